@@ -1,0 +1,224 @@
+/*
+ * sfw_hip.h — C ABI of the MI355X-native DWA rollout + social-force scorer.
+ *
+ * This is the drop-in boundary for ONE hot path of
+ * robotics-upo/social_force_window_planner: the (v,w) sample loop of
+ * SFWPlanner::findBestAction (reference src/sfw_planner.cpp:338-417) and the
+ * two single-sample calls of SFWPlanner::scoreTrajectory
+ * (src/sfw_planner.cpp:204-206 and :299-301; signature
+ * include/social_force_window_planner/sfw_planner.hpp:309-314).
+ *
+ * Plain C: POD structs, plain pointers and sizes, int status codes, no C++
+ * types and no exceptions across the boundary.  All floating point inputs are
+ * double, as in the reference; the two places where the reference computes in
+ * float (robot_radius_, normalizeAngle) are float here too.
+ *
+ * Ownership: the caller owns every buffer it passes in; the library copies
+ * what it needs into its own pinned/device buffers during the call.  Output
+ * buffers are caller-allocated.
+ *
+ * Threading: one handle = one planner = one caller thread at a time (the
+ * reference holds configuration_mutex_ for the whole findBestAction,
+ * src/sfw_planner.cpp:123-454).  Each handle owns one HIP stream.
+ *
+ * Error convention: every function returns SFW_OK (0) or a negative
+ * sfw_status.  An invalid trajectory is DATA, not an error: its cost is
+ * exactly -1.0 (src/sfw_planner.cpp:549,561,572,625), never NaN.
+ */
+#ifndef SFW_HIP_H_
+#define SFW_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFW_ABI_VERSION 1
+
+typedef enum sfw_status {
+  SFW_OK = 0,
+  SFW_ERR_INVALID_ARG = -1,  /* null pointer, negative size, ...            */
+  SFW_ERR_NO_DEVICE = -2,    /* no HIP device / kernels cannot be launched  */
+  SFW_ERR_HIP = -3,          /* a HIP runtime call failed (see last_error)  */
+  SFW_ERR_STATE = -4,        /* call order violated (e.g. no costmap set)   */
+  SFW_ERR_UNSUPPORTED = -5   /* e.g. group forces (groupId >= 0), see below */
+} sfw_status;
+
+/* Cost sentinels written into the per-sample cost vector. */
+#define SFW_COST_INVALID (-1.0) /* reference "return -1.0"                    */
+#define SFW_COST_SKIPPED (-2.0) /* the (0,0) sample the grid loop never scores
+                                   (src/sfw_planner.cpp:349-352)             */
+
+/* Arithmetic mode of the social-force kernel. */
+#define SFW_PRECISION_F64 0 /* parity mode: everything in double            */
+#define SFW_PRECISION_F32 1 /* fast mode: robot rollout + costmap in double,
+                               pedestrian dynamics in float (documented
+                               threshold-flip risk)           */
+
+/*
+ * Scoring parameters = the subset of ControllerParams
+ * (sfw_planner.hpp:55-66,186-226) that scoreTrajectory reads, plus lightsfm's
+ * sfm::Parameters (never overridden by the reference).
+ * Fill with sfw_params_default() and then override.
+ */
+typedef struct sfw_params {
+  double max_vel_x;        /* max_trans_vel, 0.7  (:58, used at :654)       */
+  double sim_time;         /* 1.0   (:61, :519)                             */
+  double sim_granularity;  /* 0.025 (:61, :519)                             */
+  float robot_radius;      /* 0.35, FLOAT on purpose (:62,:208, :617)       */
+  float reserved0;
+  double social_weight;    /* 1.2 (:65)                                     */
+  double costmap_weight;   /* 2.0                                           */
+  double angle_weight;     /* 0.7                                           */
+  double distance_weight;  /* 1.0 (:66)                                     */
+  double vel_weight;       /* 1.0                                           */
+  double robot_goal_radius; /* 0.20, the per-step robot goal (:608)         */
+  /* lightsfm sfm::Parameters defaults */
+  double sfm_force_factor_desired;  /* 2.0  */
+  double sfm_force_factor_obstacle; /* 10.0 */
+  double sfm_force_sigma_obstacle;  /* 0.2  */
+  double sfm_force_factor_social;   /* 2.1  */
+  double sfm_lambda;                /* 2.0  */
+  double sfm_gamma;                 /* 0.35 */
+  double sfm_n;                     /* 2.0  */
+  double sfm_n_prime;               /* 3.0  */
+  double sfm_relaxation_time;       /* 0.5  */
+  int32_t precision;                /* SFW_PRECISION_*                      */
+  int32_t reserved1;
+} sfw_params;
+
+/*
+ * One social agent = the fields of sfm::Agent the hot path consumes
+ * (built by SFMSensorInterface, src/sensor_interface.cpp:31-37,442-527,
+ * 552-580).  Index 0 of the array handed to sfw_set_agents is the robot
+ * (src/sfw_planner.cpp:155).
+ */
+typedef struct sfw_agent {
+  double x, y;             /* position                                      */
+  double vx, vy;           /* velocity; for the robot this is the ROBOT-LOCAL
+                              twist, as in sensor_interface.cpp:566-575     */
+  double goal_x, goal_y;   /* goals.front().center (ignored if !has_goal)   */
+  double goal_radius;      /* goals.front().radius                          */
+  double desired_velocity; /* Agent::desiredVelocity                        */
+  double radius;           /* Agent::radius                                 */
+  int32_t has_goal;        /* goals non-empty (people: 1, robot at t0: 0)   */
+  int32_t id;              /* Agent::id — the robot-on-person force skips a
+                              person whose id equals the robot's            */
+  int32_t group_id;        /* Agent::groupId; must be < 0 (group forces are
+                              not built yet -> SFW_ERR_UNSUPPORTED)         */
+  int32_t reserved;
+} sfw_agent;
+
+/* Robot pose and velocity as findBestAction hands them to scoreTrajectory.
+ * The reference truncates all six to float first (src/sfw_planner.cpp:145-152)
+ * — the host mirror does that; the ABI takes whatever it is given. */
+typedef struct sfw_robot_state {
+  double x, y, theta;
+  double vx, vy, vtheta;
+} sfw_robot_state;
+
+/* Per-call sample-independent arguments of scoreTrajectory. */
+typedef struct sfw_goal_args {
+  double acc_x, acc_y, acc_theta; /* max_trans_acc_, 0.0, max_rot_acc_      */
+  double wpx, wpy;                /* current way-point                      */
+} sfw_goal_args;
+
+/* Result of the selection rule (src/sfw_planner.cpp:394-414, :426-468). */
+typedef struct sfw_best {
+  int64_t index;    /* iv*nw+iw of the winner, -1 if no sample is selectable */
+  double cost;      /* winner's cost, -1.0 if none                           */
+  double vx, vy, vtheta; /* cmd_vel (0,0,0 if none)                          */
+  int64_t n_valid;  /* samples with cost >= 0                                */
+} sfw_best;
+
+/* 4-double key used for the multi-GPU exchange: lexicographic minimum over
+ * ranks reproduces the reference's selection order exactly
+ * (cost up, linvel down, |angvel| up, iteration index down). */
+typedef struct sfw_best_key {
+  double cost;        /* +inf if the rank holds no selectable sample         */
+  double neg_linvel;  /* -linvel                                             */
+  double abs_angvel;  /* |angvel|                                            */
+  double neg_index;   /* -(global iteration index)                           */
+} sfw_best_key;
+
+typedef struct sfw_planner_s *sfw_handle;
+
+/* ---- lifecycle --------------------------------------------------------- */
+void sfw_params_default(sfw_params *p);
+int sfw_abi_version(void);
+/* device: HIP device ordinal.  Fails with SFW_ERR_NO_DEVICE when no GPU is
+ * visible — there is no CPU fallback in this library. */
+int sfw_create(const sfw_params *params, int device, sfw_handle *out);
+int sfw_destroy(sfw_handle h);
+/* The reference re-reads its parameters on every cycle (:125). */
+int sfw_set_params(sfw_handle h, const sfw_params *params);
+const char *sfw_last_error(sfw_handle h);
+
+/* ---- world state (replaces const Costmap2D& / footprint_spec_ / getAgents) */
+/* cells: row-major, y outer, cells[my*size_x+mx] == Costmap2D::getCost(mx,my).
+ * Snapshot copy (the reference reads nav2's live costmap, sfw_planner.hpp:362). */
+int sfw_set_costmap(sfw_handle h, const uint8_t *cells, uint32_t size_x,
+                    uint32_t size_y, double origin_x, double origin_y,
+                    double resolution);
+/* xy: K points (x0,y0,x1,y1,...) in the robot frame = footprint_spec_
+ * (src/sfw_planner.cpp:32).  K < 3 => centre-cell check only
+ * (src/costmap_model.cpp:41-48). */
+int sfw_set_footprint(sfw_handle h, const double *xy, int32_t K);
+/* agents[0] = robot.  obstacles_xy: O laser points shared by every agent's
+ * obstacles1 (src/sensor_interface.cpp:513-524). */
+int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A,
+                   const double *obstacles_xy, int32_t O);
+
+/* ---- scoring ----------------------------------------------------------- */
+/*
+ * The grid loop of findBestAction (src/sfw_planner.cpp:345-417): for every
+ * (linvels[iv], angvels[iw]), iv outer, cost = scoreTrajectory(rs, linvel,
+ * 0.0, angvel, args...); costs_out[iv*nw+iw] receives it (SFW_COST_SKIPPED
+ * for the (0,0) sample).  best_out receives the reference's selection.
+ * Blocking: returns after the D2H copy.  costs_out / best_out may be NULL.
+ */
+int sfw_score_grid(sfw_handle h, const sfw_robot_state *rs,
+                   const double *linvels, int32_t nv, const double *angvels,
+                   int32_t nw, const sfw_goal_args *args, double *costs_out,
+                   sfw_best *best_out);
+
+/*
+ * One scoreTrajectory call (the two scalar call sites :204-206, :299-301).
+ * points_xyth (nullable) receives up to points_cap (x,y,theta) triples = the
+ * Trajectory points (src/sfw_planner.cpp:578); *n_points their count.
+ */
+int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp,
+                  double vy_samp, double vtheta_samp, const sfw_goal_args *args,
+                  double *cost_out, double *points_xyth, int32_t points_cap,
+                  int32_t *n_points);
+
+/* ---- device-resident pipeline (what sfw_score_grid is made of) --------- */
+/* Stage one grid call: H2D of the sample vectors + robot state.  index_base
+ * is the global iteration index of this rank's first sample (multi-GPU
+ * sharding by linvel rows); 0 on a single GPU. */
+int sfw_grid_stage(sfw_handle h, const sfw_robot_state *rs,
+                   const double *linvels, int32_t nv, const double *angvels,
+                   int32_t nw, const sfw_goal_args *args, int64_t index_base);
+/* Enqueue rollout + social-force + argmin kernels on the handle's stream.
+ * Everything stays in HBM; no host sync. */
+int sfw_grid_launch(sfw_handle h);
+int sfw_grid_sync(sfw_handle h);
+/* D2H of the cost vector (nullable) and the local selection (nullable). */
+int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out,
+                   sfw_best_key *key_out);
+/* HIP-event time (ms) of the most recent sfw_grid_launch:
+ * which = 0 whole launch, 1 rollout kernel, 2 social-force kernel, 3 argmin. */
+int sfw_last_launch_ms(sfw_handle h, int32_t which, float *ms_out);
+/* Optional dump of the per-step robot poses of sample `index` of the last
+ * launch (Trajectory points for RViz markers, :366-374). */
+int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth,
+                    int32_t points_cap, int32_t *n_points);
+/* Raw HIP stream (hipStream_t) the handle launches on, for callers that want
+ * to record their own events. */
+void *sfw_stream(sfw_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFW_HIP_H_ */

@@ -1,0 +1,542 @@
+// sfw_oracle.cpp — CPU restatement of the reference's DWA rollout + social-force
+// scoring path.  TEST INFRASTRUCTURE ONLY: nothing in the product path
+// (social_force_window_planner_amd/, include/) may include, link or call this
+// file.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+// use it, and only as the checker / the timed CPU baseline.
+//
+// PARITY STATUS
+//   * Bresenham cell sequences: pinned against the reference's own
+//     line_iterator.hpp (oracle/_ref, tests/test_oracle_ref.py).
+//   * scoreTrajectory / computeSocialWork / selection rule / footprint cost:
+//     restated from the reference text (citations below); the reference has no
+//     tests or golden vectors and its .cpp files cannot be compiled here
+//     (32 missing ROS2/nav2/lightsfm headers), so these are checked by
+//     closed-form cases only.
+//   * lightsfm (robotics-upo/lightsfm, header-only, NO pinned version,
+//     reference package.xml:31) and nav2_costmap_2d::Costmap2D (ROS 2 Foxy) are
+//     absent from /root/reference and from this image.  Their arithmetic is
+//     restated from the published model (Moussaid et al. 2009/2010 social
+//     force with velocity/angle interaction terms) and the call sites in
+//     src/sfw_planner.cpp:592,594,697.  => PARITY UNPINNED at those two
+//     boundaries.
+//
+// All arithmetic is double except where the reference itself uses float
+// (normalizeAngle, robot_radius_).  "ref:" comments cite /root/reference.
+
+#include "../include/sfw_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace sfwo {
+
+// ---------------------------------------------------------------------------
+// utils::Vector2d / utils::Angle subset (lightsfm vector2d.hpp / angle.hpp)
+// ---------------------------------------------------------------------------
+struct V2 {
+  double x = 0.0, y = 0.0;
+};
+static inline V2 operator+(V2 a, V2 b) { return {a.x + b.x, a.y + b.y}; }
+static inline V2 operator-(V2 a, V2 b) { return {a.x - b.x, a.y - b.y}; }
+static inline V2 operator*(double s, V2 a) { return {s * a.x, s * a.y}; }
+static inline V2 operator*(V2 a, double s) { return {a.x * s, a.y * s}; }
+static inline V2 operator/(V2 a, double s) { return {a.x / s, a.y / s}; }
+static inline V2 operator-(V2 a) { return {-a.x, -a.y}; }
+static inline double norm(V2 a) { return std::sqrt(a.x * a.x + a.y * a.y); }
+// Vector2d::normalized(): leaves a zero vector untouched.
+static inline V2 normalized(V2 a) {
+  double n = norm(a);
+  if (n > 0.0) return {a.x / n, a.y / n};
+  return a;
+}
+static inline V2 left_normal(V2 a) { return {-a.y, a.x}; }
+// utils::Angle keeps its value in (-pi, pi].
+static inline double wrap_angle(double v) {
+  while (v <= -M_PI) v += 2.0 * M_PI;
+  while (v > M_PI) v -= 2.0 * M_PI;
+  return v;
+}
+static inline double angle_of(V2 a) { return wrap_angle(std::atan2(a.y, a.x)); }
+static inline int angle_sign(double v) { return v == 0.0 ? 0 : (v > 0.0 ? 1 : -1); }
+
+// ---------------------------------------------------------------------------
+// sfm::Agent subset (fields the hot path reads)
+// ---------------------------------------------------------------------------
+struct Goal {
+  V2 center;
+  double radius = 0.0;
+};
+struct Agent {
+  V2 position, velocity;
+  double yaw = 0.0;
+  double desiredVelocity = 0.6, radius = 0.35;
+  std::vector<Goal> goals;  // std::list in lightsfm; front() = [0]
+  bool cyclicGoals = false, teleoperated = false;
+  double linearVelocity = 0.0, angularVelocity = 0.0;
+  int groupId = -1, id = 0;
+  V2 desiredForce, obstacleForce, socialForce, globalForce;
+  const std::vector<V2> *obstacles1 = nullptr;  // shared laser points
+};
+
+struct World {
+  sfw_params p;
+  // Costmap2D stand-in
+  std::vector<uint8_t> cells;
+  uint32_t size_x = 0, size_y = 0;
+  double origin_x = 0, origin_y = 0, resolution = 1;
+  std::vector<V2> footprint;
+  std::vector<Agent> agents;
+  std::vector<V2> obstacles;
+  std::string err;
+
+  // nav2_costmap_2d::Costmap2D::worldToMap (Foxy): reject below origin,
+  // truncate, then bound check.
+  bool worldToMap(double wx, double wy, unsigned &mx, unsigned &my) const {
+    if (wx < origin_x || wy < origin_y) return false;
+    mx = static_cast<unsigned>((wx - origin_x) / resolution);
+    my = static_cast<unsigned>((wy - origin_y) / resolution);
+    return mx < size_x && my < size_y;
+  }
+  uint8_t getCost(unsigned mx, unsigned my) const {
+    return cells[static_cast<size_t>(my) * size_x + mx];
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Bresenham walk.  ref: include/social_force_window_planner/line_iterator.hpp:39-97
+// Emits max(|dx|,|dy|)+1 cells starting at (x0,y0).
+// ---------------------------------------------------------------------------
+template <class F>
+static inline void bresenham(int x0, int y0, int x1, int y1, F &&visit) {
+  const int adx = std::abs(x1 - x0), ady = std::abs(y1 - y0);
+  const int sx = (x1 >= x0) ? 1 : -1, sy = (y1 >= y0) ? 1 : -1;
+  const bool x_major = adx >= ady;
+  const int den = x_major ? adx : ady;
+  const int add = x_major ? ady : adx;
+  int num = den / 2, x = x0, y = y0;
+  for (int n = 0; n <= den; ++n) {
+    if (!visit(x, y)) return;
+    num += add;
+    if (num >= den) {
+      num -= den;
+      if (x_major) y += sy; else x += sx;   // minor axis step
+    }
+    if (x_major) x += sx; else y += sy;     // major axis step
+  }
+}
+
+// ref: src/costmap_model.cpp:112-121  (253 is NOT rejected on edges)
+static inline double point_cost(const World &w, int x, int y) {
+  uint8_t c = w.getCost(static_cast<unsigned>(x), static_cast<unsigned>(y));
+  if (c == 255) return -2.0;
+  if (c == 254) return -1.0;
+  return c;
+}
+// ref: src/costmap_model.cpp:95-110
+static double line_cost(const World &w, int x0, int x1, int y0, int y1) {
+  double best = 0.0, bad = 0.0;
+  bool hit = false;
+  bresenham(x0, y0, x1, y1, [&](int x, int y) {
+    double pc = point_cost(w, x, y);
+    if (pc < 0) { bad = pc; hit = true; return false; }
+    if (best < pc) best = pc;
+    return true;
+  });
+  return hit ? bad : best;
+}
+// ref: src/costmap_model.cpp:21-92
+static double footprint_cost_oriented(const World &w, V2 pos, const std::vector<V2> &fp) {
+  unsigned cx, cy;
+  if (!w.worldToMap(pos.x, pos.y, cx, cy)) return -3.0;
+  if (fp.size() < 3) {
+    uint8_t c = w.getCost(cx, cy);
+    if (c == 255) return -2.0;
+    if (c == 254 || c == 253) return -1.0;
+    return c;
+  }
+  double fc = 0.0;
+  const size_t K = fp.size();
+  for (size_t e = 0; e < K; ++e) {
+    // edges 0..K-2 join fp[e]->fp[e+1]; the closing edge joins back()->front()
+    const V2 a = (e + 1 < K) ? fp[e] : fp[K - 1];
+    const V2 b = (e + 1 < K) ? fp[e + 1] : fp[0];
+    unsigned x0, y0, x1, y1;
+    if (!w.worldToMap(a.x, a.y, x0, y0)) return -3.0;
+    if (!w.worldToMap(b.x, b.y, x1, y1)) return -3.0;
+    double lc = line_cost(w, (int)x0, (int)x1, (int)y0, (int)y1);
+    fc = std::max(lc, fc);
+    if (lc < 0) return lc;
+  }
+  return fc;
+}
+// ref: include/social_force_window_planner/world_model.hpp:45-75
+static double footprint_cost(const World &w, double x, double y, double th) {
+  const double c = std::cos(th), s = std::sin(th);
+  std::vector<V2> oriented;
+  oriented.reserve(w.footprint.size());
+  for (const V2 &q : w.footprint)
+    oriented.push_back({x + (q.x * c - q.y * s), y + (q.x * s + q.y * c)});
+  return footprint_cost_oriented(w, {x, y}, oriented);
+}
+
+// ---------------------------------------------------------------------------
+// lightsfm subset (UNPINNED restatement)
+// ---------------------------------------------------------------------------
+static V2 sfm_desired(const sfw_params &p, Agent &a) {
+  V2 dir;
+  if (!a.goals.empty() && norm(a.goals.front().center - a.position) > a.goals.front().radius) {
+    dir = normalized(a.goals.front().center - a.position);
+    a.desiredForce = p.sfm_force_factor_desired * (dir * a.desiredVelocity - a.velocity) /
+                     p.sfm_relaxation_time;
+  } else {
+    a.desiredForce = -a.velocity / p.sfm_relaxation_time;
+  }
+  return dir;
+}
+static void sfm_obstacle(const sfw_params &p, Agent &a) {
+  a.obstacleForce = {0, 0};
+  if (a.obstacles1 && !a.obstacles1->empty()) {
+    for (const V2 &o : *a.obstacles1) {
+      V2 md = a.position - o;
+      double dist = norm(md) - a.radius;
+      a.obstacleForce = a.obstacleForce + p.sfm_force_factor_obstacle *
+                                              std::exp(-dist / p.sfm_force_sigma_obstacle) *
+                                              normalized(md);
+    }
+    a.obstacleForce = a.obstacleForce / (double)a.obstacles1->size();
+  }
+}
+// Force exerted on `me` by `other` (one term of computeSocialForce).
+static inline V2 sfm_pair(const sfw_params &p, const Agent &me, const Agent &other) {
+  V2 diff = other.position - me.position;
+  V2 diffDir = normalized(diff);
+  V2 velDiff = me.velocity - other.velocity;
+  V2 inter = p.sfm_lambda * velDiff + diffDir;
+  double interLen = norm(inter);
+  V2 interDir = inter / interLen;
+  double theta = wrap_angle(angle_of(diffDir) - angle_of(interDir));
+  double B = p.sfm_gamma * interLen;
+  double sq_v = p.sfm_n_prime * B * theta, sq_a = p.sfm_n * B * theta;
+  double fv = -std::exp(-norm(diff) / B - sq_v * sq_v);
+  double fa = -(double)angle_sign(theta) * std::exp(-norm(diff) / B - sq_a * sq_a);
+  return p.sfm_force_factor_social * (fv * interDir + fa * left_normal(interDir));
+}
+// sfm::SFM.computeForces(std::vector<Agent>&)   (call site src/sfw_planner.cpp:592)
+static void sfm_compute_forces(const sfw_params &p, std::vector<Agent> &ag) {
+  for (size_t i = 0; i < ag.size(); ++i) {
+    sfm_desired(p, ag[i]);
+    sfm_obstacle(p, ag[i]);
+    ag[i].socialForce = {0, 0};
+    for (size_t j = 0; j < ag.size(); ++j) {
+      if (j == i) continue;
+      ag[i].socialForce = ag[i].socialForce + sfm_pair(p, ag[i], ag[j]);
+    }
+    // groupForce == 0: every agent has groupId < 0 (enforced at set_agents)
+    ag[i].globalForce = ag[i].desiredForce + ag[i].socialForce + ag[i].obstacleForce;
+  }
+}
+// sfm::SFM.computeForces(Agent& me, std::vector<Agent>&)  (call site :697);
+// skips by id, not by index.
+static void sfm_compute_forces_single(const sfw_params &p, Agent &me, const std::vector<Agent> &others) {
+  sfm_desired(p, me);
+  sfm_obstacle(p, me);
+  me.socialForce = {0, 0};
+  for (const Agent &o : others) {
+    if (o.id == me.id) continue;
+    me.socialForce = me.socialForce + sfm_pair(p, me, o);
+  }
+  me.globalForce = me.desiredForce + me.socialForce + me.obstacleForce;
+}
+// sfm::SFM.updatePosition   (call site src/sfw_planner.cpp:594)
+static void sfm_update_position(std::vector<Agent> &ag, double dt) {
+  for (Agent &a : ag) {
+    if (a.teleoperated) {
+      double imd = a.linearVelocity * dt;
+      double h = a.yaw + a.angularVelocity * dt * 0.5;
+      a.position = a.position + V2{imd * std::cos(h), imd * std::sin(h)};
+      a.yaw = wrap_angle(a.yaw + wrap_angle(a.angularVelocity * dt));
+      a.velocity = {a.linearVelocity * std::cos(a.yaw), a.linearVelocity * std::sin(a.yaw)};
+    } else {
+      a.velocity = a.velocity + a.globalForce * dt;
+      if (norm(a.velocity) > a.desiredVelocity)
+        a.velocity = normalized(a.velocity) * a.desiredVelocity;
+      a.yaw = angle_of(a.velocity);
+      a.position = a.position + a.velocity * dt;
+    }
+    if (!a.goals.empty() && norm(a.goals.front().center - a.position) <= a.goals.front().radius) {
+      Goal g = a.goals.front();
+      a.goals.erase(a.goals.begin());
+      if (a.cyclicGoals) a.goals.push_back(g);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Planner helpers.  ref: include/.../sfw_planner.hpp:399-463
+// ---------------------------------------------------------------------------
+static inline float normalize_angle_f(float val, float mn, float mx) {
+  if (val >= mn) return mn + std::fmod(val - mn, mx - mn);
+  return mx - std::fmod(mn - val, mx - mn);
+}
+static inline double new_velocity(double vg, double vi, double a_max, double dt) {
+  if ((vg - vi) >= 0) return std::min(vg, vi + a_max * dt);
+  return std::max(vg, vi - a_max * dt);
+}
+
+// ref: src/sfw_planner.cpp:678-705
+static double social_work(const sfw_params &p, const std::vector<Agent> &ag) {
+  double wr = norm(ag[0].socialForce) + norm(ag[0].obstacleForce);
+  std::vector<Agent> robot_only(1, ag[0]);
+  double wp = 0.0;
+  for (size_t i = 1; i < ag.size(); ++i) {
+    Agent person = ag[i];
+    sfm_compute_forces_single(p, person, robot_only);
+    wp += norm(person.socialForce);
+  }
+  return wr + wp;
+}
+
+static inline int num_steps_of(const sfw_params &p) {
+  int n = int(p.sim_time / p.sim_granularity + 0.5);  // ref :519
+  return n == 0 ? 1 : n;                               // ref :523-525
+}
+
+// ref: src/sfw_planner.cpp:475-676.  pts (nullable) collects Trajectory points.
+static double score_trajectory(const World &w, double x, double y, double theta, double vx,
+                               double vy, double vtheta, double vx_samp, double vy_samp,
+                               double vtheta_samp, double acc_x, double acc_y, double acc_theta,
+                               double wpx, double wpy, std::vector<double> *pts) {
+  const sfw_params &p = w.p;
+  std::vector<Agent> my = w.agents;  // per-sample deep copy, ref :486
+  double x_i = x, y_i = y, th_i = theta;
+  double vx_i = vx, vy_i = vy, vth_i = vtheta;
+  const int S = num_steps_of(p);
+  const double dt = p.sim_time / S;  // ref :527
+  double sw = 0.0, cm = 0.0;
+  if (pts) pts->clear();
+  const double rr = (double)(p.robot_radius * p.robot_radius);  // float product, ref :617
+
+  for (int i = 0; i < S; ++i) {
+    unsigned cx, cy;
+    if (!w.worldToMap(x_i, y_i, cx, cy)) return -1.0;          // ref :545-550
+    double fc = footprint_cost(w, x_i, y_i, th_i);             // ref :553
+    if (fc >= 254.0) return -1.0;                              // ref :555
+    if (fc < 0) return -1.0;                                   // ref :565
+    cm += fc / 255.0;                                          // ref :575
+    if (pts) { pts->push_back(x_i); pts->push_back(y_i); pts->push_back(th_i); }
+
+    vx_i = new_velocity(vx_samp, vx_i, acc_x, dt);             // ref :581-583
+    vy_i = new_velocity(vy_samp, vy_i, acc_y, dt);
+    vth_i = new_velocity(vtheta_samp, vth_i, acc_theta, dt);
+    // ref :586-588 — new velocities, OLD theta for both x and y
+    const double xn = x_i + (vx_i * std::cos(th_i) + vy_i * std::cos(M_PI_2 + th_i)) * dt;
+    const double yn = y_i + (vx_i * std::sin(th_i) + vy_i * std::sin(M_PI_2 + th_i)) * dt;
+    x_i = xn; y_i = yn;
+    th_i = th_i + vth_i * dt;
+
+    if (!my.empty()) {
+      sfm_compute_forces(p, my);                               // ref :592
+      sfm_update_position(my, dt);                             // ref :594
+      Agent &r = my[0];                                        // ref :600-610
+      r.position = {x_i, y_i};
+      r.yaw = wrap_angle(th_i);
+      r.linearVelocity = hypotf((float)vx_i, (float)vy_i);
+      r.angularVelocity = vth_i;
+      r.velocity = {vx_i, vy_i};
+      r.goals.assign(1, Goal{{wpx, wpy}, p.robot_goal_radius});
+      for (size_t j = 1; j < my.size(); ++j) {                 // ref :613-627
+        double dx = r.position.x - my[j].position.x, dy = r.position.y - my[j].position.y;
+        if (dx * dx + dy * dy <= rr) return -1.0;
+      }
+      sw += social_work(p, my);                                // ref :629
+    }
+  }
+  // ref :643-667
+  const double dx = wpx - x_i, dy = wpy - y_i;
+  const double d = dx * dx + dy * dy;
+  double ang = std::atan2(dy, dx) - th_i;
+  ang = normalize_angle_f((float)ang, (float)-M_PI, (float)M_PI);
+  ang = std::fabs((float)ang) / M_PI;
+  const double vel = std::fabs(p.max_vel_x - vx_i) / p.max_vel_x;
+  cm = cm / S;
+  return p.vel_weight * vel + p.distance_weight * d + p.angle_weight * ang +
+         p.costmap_weight * cm + p.social_weight * sw;
+}
+
+// Sequential selection, literally as the reference scans.  ref :338-417, :426-468
+static void select_best(const double *lin, int nv, const double *ang, int nw,
+                        const double *costs, sfw_best *out) {
+  double best_cost = 10000.0, bxv = 0.0, bth = 0.0, btc = -1.0;
+  int64_t best_i = -1, n_valid = 0;
+  double vx = 0.0, vt = 0.0;
+  for (int iv = 0; iv < nv; ++iv)
+    for (int iw = 0; iw < nw; ++iw) {
+      const int64_t i = (int64_t)iv * nw + iw;
+      const double linvel = lin[iv], angvel = ang[iw];
+      if (linvel == 0.0 && angvel == 0.0) continue;
+      const double c = costs[i];
+      if (c >= 0.0) ++n_valid;
+      if (c >= 0.0 && c <= best_cost) {
+        if (c == best_cost && linvel < bxv) continue;
+        if (c == best_cost && linvel == bxv && std::fabs(angvel) > std::fabs(bth)) continue;
+        bxv = linvel; bth = angvel; btc = c;
+        best_cost = c; best_i = i; vx = linvel; vt = angvel;
+      }
+    }
+  out->n_valid = n_valid;
+  if (btc != -1.0) { out->index = best_i; out->cost = btc; out->vx = vx; out->vy = 0.0; out->vtheta = vt; }
+  else { out->index = -1; out->cost = -1.0; out->vx = out->vy = out->vtheta = 0.0; }
+}
+
+}  // namespace sfwo
+
+// ===========================================================================
+// C entry points (same shapes as include/sfw_hip.h, prefix sfwo_)
+// ===========================================================================
+using sfwo::World;
+extern "C" {
+
+int sfwo_create(const sfw_params *p, void **out) {
+  if (!p || !out) return SFW_ERR_INVALID_ARG;
+  World *w = new World();
+  w->p = *p;
+  *out = w;
+  return SFW_OK;
+}
+int sfwo_destroy(void *h) { delete static_cast<World *>(h); return SFW_OK; }
+int sfwo_set_params(void *h, const sfw_params *p) {
+  if (!h || !p) return SFW_ERR_INVALID_ARG;
+  static_cast<World *>(h)->p = *p;
+  return SFW_OK;
+}
+int sfwo_set_costmap(void *h, const uint8_t *cells, uint32_t sx, uint32_t sy, double ox,
+                     double oy, double res) {
+  if (!h || !cells || sx == 0 || sy == 0 || !(res > 0)) return SFW_ERR_INVALID_ARG;
+  World *w = static_cast<World *>(h);
+  w->cells.assign(cells, cells + (size_t)sx * sy);
+  w->size_x = sx; w->size_y = sy; w->origin_x = ox; w->origin_y = oy; w->resolution = res;
+  return SFW_OK;
+}
+int sfwo_set_footprint(void *h, const double *xy, int32_t K) {
+  if (!h || K < 0 || (K > 0 && !xy)) return SFW_ERR_INVALID_ARG;
+  World *w = static_cast<World *>(h);
+  w->footprint.clear();
+  for (int i = 0; i < K; ++i) w->footprint.push_back({xy[2 * i], xy[2 * i + 1]});
+  return SFW_OK;
+}
+int sfwo_set_agents(void *h, const sfw_agent *a, int32_t A, const double *obs, int32_t O) {
+  if (!h || A < 0 || O < 0 || (A > 0 && !a) || (O > 0 && !obs)) return SFW_ERR_INVALID_ARG;
+  World *w = static_cast<World *>(h);
+  for (int i = 0; i < A; ++i)
+    if (a[i].group_id >= 0) return SFW_ERR_UNSUPPORTED;
+  w->obstacles.clear();
+  for (int i = 0; i < O; ++i) w->obstacles.push_back({obs[2 * i], obs[2 * i + 1]});
+  w->agents.clear();
+  for (int i = 0; i < A; ++i) {
+    sfwo::Agent g;
+    g.position = {a[i].x, a[i].y};
+    g.velocity = {a[i].vx, a[i].vy};
+    g.desiredVelocity = a[i].desired_velocity;
+    g.radius = a[i].radius;
+    if (a[i].has_goal) g.goals.push_back({{a[i].goal_x, a[i].goal_y}, a[i].goal_radius});
+    g.id = a[i].id;
+    g.groupId = a[i].group_id;
+    g.teleoperated = (i == 0);  // ref: src/sensor_interface.cpp:36, :489
+    g.linearVelocity = sfwo::norm(g.velocity);
+    g.obstacles1 = &w->obstacles;
+    w->agents.push_back(g);
+  }
+  return SFW_OK;
+}
+static int check_world(const World *w) {
+  if (w->cells.empty()) return SFW_ERR_STATE;
+  return SFW_OK;
+}
+int sfwo_score_one(void *h, const sfw_robot_state *rs, double vxs, double vys, double vths,
+                   const sfw_goal_args *g, double *cost_out, double *pts, int32_t cap,
+                   int32_t *n_pts) {
+  if (!h || !rs || !g || !cost_out) return SFW_ERR_INVALID_ARG;
+  World *w = static_cast<World *>(h);
+  if (int e = check_world(w)) return e;
+  std::vector<double> tmp;
+  *cost_out = sfwo::score_trajectory(*w, rs->x, rs->y, rs->theta, rs->vx, rs->vy, rs->vtheta, vxs,
+                                     vys, vths, g->acc_x, g->acc_y, g->acc_theta, g->wpx, g->wpy,
+                                     &tmp);
+  int n = (int)(tmp.size() / 3);
+  if (n_pts) *n_pts = n;
+  if (pts) std::memcpy(pts, tmp.data(), sizeof(double) * 3 * std::min(n, (int)cap));
+  return SFW_OK;
+}
+// n_threads <= 1: the reference's serial double loop.  > 1: one sample per
+// OpenMP task (CPU baseline "all cores" variant).
+int sfwo_score_grid(void *h, const sfw_robot_state *rs, const double *lin, int32_t nv,
+                    const double *ang, int32_t nw, const sfw_goal_args *g, double *costs_out,
+                    sfw_best *best_out, int32_t n_threads) {
+  if (!h || !rs || !g || !lin || !ang || nv <= 0 || nw <= 0) return SFW_ERR_INVALID_ARG;
+  World *w = static_cast<World *>(h);
+  if (int e = check_world(w)) return e;
+  const int64_t T = (int64_t)nv * nw;
+  std::vector<double> local;
+  double *costs = costs_out;
+  if (!costs) { local.resize(T); costs = local.data(); }
+#ifdef _OPENMP
+  if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
+#endif
+  for (int64_t i = 0; i < T; ++i) {
+    const double linvel = lin[i / nw], angvel = ang[i % nw];
+    if (linvel == 0.0 && angvel == 0.0) { costs[i] = SFW_COST_SKIPPED; continue; }
+    costs[i] = sfwo::score_trajectory(*w, rs->x, rs->y, rs->theta, rs->vx, rs->vy, rs->vtheta,
+                                      linvel, 0.0, angvel, g->acc_x, g->acc_y, g->acc_theta,
+                                      g->wpx, g->wpy, nullptr);
+  }
+  if (best_out) sfwo::select_best(lin, nv, ang, nw, costs, best_out);
+  return SFW_OK;
+}
+// Exposed pieces for known-answer tests.
+int sfwo_select_best(const double *lin, int32_t nv, const double *ang, int32_t nw,
+                     const double *costs, sfw_best *out) {
+  if (!lin || !ang || !costs || !out) return SFW_ERR_INVALID_ARG;
+  sfwo::select_best(lin, nv, ang, nw, costs, out);
+  return SFW_OK;
+}
+int sfwo_line_cells(int x0, int y0, int x1, int y1, int32_t *xy_out, int32_t cap) {
+  int n = 0;
+  sfwo::bresenham(x0, y0, x1, y1, [&](int x, int y) {
+    if (n < cap) { xy_out[2 * n] = x; xy_out[2 * n + 1] = y; }
+    ++n;
+    return true;
+  });
+  return n;
+}
+double sfwo_footprint_cost(void *h, double x, double y, double th) {
+  return sfwo::footprint_cost(*static_cast<World *>(h), x, y, th);
+}
+// Force on agent `me` from agent `other` (one social-force term).
+int sfwo_pair_force(const sfw_params *p, const sfw_agent *me, const sfw_agent *other, double *fxy) {
+  sfwo::Agent a, b;
+  a.position = {me->x, me->y}; a.velocity = {me->vx, me->vy};
+  b.position = {other->x, other->y}; b.velocity = {other->vx, other->vy};
+  sfwo::V2 f = sfwo::sfm_pair(*p, a, b);
+  fxy[0] = f.x; fxy[1] = f.y;
+  return SFW_OK;
+}
+float sfwo_normalize_angle(float v, float mn, float mx) { return sfwo::normalize_angle_f(v, mn, mx); }
+int sfwo_num_steps(const sfw_params *p) { return sfwo::num_steps_of(*p); }
+int sfwo_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+}  // extern "C"

@@ -1,0 +1,147 @@
+"""ctypes mirror of include/sfw_hip.h (POD structs + status codes).
+
+Shared by the product binding (planner.py) and by the oracle binding under
+oracle/ — the structs are the ABI, not an implementation.
+"""
+import ctypes as C
+
+SFW_OK = 0
+SFW_ERR_INVALID_ARG = -1
+SFW_ERR_NO_DEVICE = -2
+SFW_ERR_HIP = -3
+SFW_ERR_STATE = -4
+SFW_ERR_UNSUPPORTED = -5
+
+SFW_COST_INVALID = -1.0
+SFW_COST_SKIPPED = -2.0
+
+SFW_PRECISION_F64 = 0
+SFW_PRECISION_F32 = 1
+
+
+class SfwParams(C.Structure):
+    _fields_ = [
+        ("max_vel_x", C.c_double),
+        ("sim_time", C.c_double),
+        ("sim_granularity", C.c_double),
+        ("robot_radius", C.c_float),
+        ("reserved0", C.c_float),
+        ("social_weight", C.c_double),
+        ("costmap_weight", C.c_double),
+        ("angle_weight", C.c_double),
+        ("distance_weight", C.c_double),
+        ("vel_weight", C.c_double),
+        ("robot_goal_radius", C.c_double),
+        ("sfm_force_factor_desired", C.c_double),
+        ("sfm_force_factor_obstacle", C.c_double),
+        ("sfm_force_sigma_obstacle", C.c_double),
+        ("sfm_force_factor_social", C.c_double),
+        ("sfm_lambda", C.c_double),
+        ("sfm_gamma", C.c_double),
+        ("sfm_n", C.c_double),
+        ("sfm_n_prime", C.c_double),
+        ("sfm_relaxation_time", C.c_double),
+        ("precision", C.c_int32),
+        ("reserved1", C.c_int32),
+    ]
+
+
+def default_params(**overrides):
+    """ControllerParams defaults (reference sfw_planner.hpp:56-66) plus
+    lightsfm's sfm::Parameters defaults."""
+    p = SfwParams()
+    p.max_vel_x = 0.7
+    p.sim_time = 1.0
+    p.sim_granularity = 0.025
+    p.robot_radius = 0.35
+    p.social_weight = 1.2
+    p.costmap_weight = 2.0
+    p.angle_weight = 0.7
+    p.distance_weight = 1.0
+    p.vel_weight = 1.0
+    p.robot_goal_radius = 0.20
+    p.sfm_force_factor_desired = 2.0
+    p.sfm_force_factor_obstacle = 10.0
+    p.sfm_force_sigma_obstacle = 0.2
+    p.sfm_force_factor_social = 2.1
+    p.sfm_lambda = 2.0
+    p.sfm_gamma = 0.35
+    p.sfm_n = 2.0
+    p.sfm_n_prime = 3.0
+    p.sfm_relaxation_time = 0.5
+    p.precision = SFW_PRECISION_F64
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(f"sfw_params has no field {k!r}")
+        setattr(p, k, v)
+    return p
+
+
+class SfwAgent(C.Structure):
+    _fields_ = [
+        ("x", C.c_double),
+        ("y", C.c_double),
+        ("vx", C.c_double),
+        ("vy", C.c_double),
+        ("goal_x", C.c_double),
+        ("goal_y", C.c_double),
+        ("goal_radius", C.c_double),
+        ("desired_velocity", C.c_double),
+        ("radius", C.c_double),
+        ("has_goal", C.c_int32),
+        ("id", C.c_int32),
+        ("group_id", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class SfwRobotState(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("x", "y", "theta", "vx", "vy", "vtheta")]
+
+
+class SfwGoalArgs(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("acc_x", "acc_y", "acc_theta", "wpx", "wpy")]
+
+
+class SfwBest(C.Structure):
+    _fields_ = [
+        ("index", C.c_int64),
+        ("cost", C.c_double),
+        ("vx", C.c_double),
+        ("vy", C.c_double),
+        ("vtheta", C.c_double),
+        ("n_valid", C.c_int64),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class SfwBestKey(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("cost", "neg_linvel", "abs_angvel", "neg_index")]
+
+    def as_tuple(self):
+        return (self.cost, self.neg_linvel, self.abs_angvel, self.neg_index)
+
+
+# Every symbol include/sfw_hip.h declares (checked by tests/test_abi.py).
+EXPORTED_SYMBOLS = (
+    "sfw_params_default",
+    "sfw_abi_version",
+    "sfw_create",
+    "sfw_destroy",
+    "sfw_set_params",
+    "sfw_last_error",
+    "sfw_set_costmap",
+    "sfw_set_footprint",
+    "sfw_set_agents",
+    "sfw_score_grid",
+    "sfw_score_one",
+    "sfw_grid_stage",
+    "sfw_grid_launch",
+    "sfw_grid_sync",
+    "sfw_grid_fetch",
+    "sfw_last_launch_ms",
+    "sfw_grid_points",
+    "sfw_stream",
+)
