@@ -1,0 +1,547 @@
+// sfw_capi.hip — host side of the C ABI declared in include/sfw_hip.h.
+// Owns the device buffers, the handle's HIP stream and events, and sequences
+// the three kernels of sfw_kernels.hip.  There is NO CPU fallback: without a
+// HIP device sfw_create fails with SFW_ERR_NO_DEVICE.
+
+#include "sfw_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+template <typename T> struct dev_buf {
+  T *p = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 16;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct sfw_planner_s {
+  sfw_params params;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::string err;
+
+  // world state
+  dev_buf<uint8_t> cells;
+  uint32_t size_x = 0, size_y = 0;
+  double origin_x = 0, origin_y = 0, resolution = 0;
+  bool have_costmap = false;
+  dev_buf<double> footprint;
+  int K = 0;
+  dev_buf<double> agent_pos, agent_vel, obstacles;
+  dev_buf<sfw_agent_const> agent_c;
+  int A = 0, O = 0;
+
+  // staged grid
+  dev_buf<double> linvels, angvels;
+  std::vector<double> h_lin, h_ang;
+  int nv = 0, nw = 0;
+  sfw_robot_state rs{};
+  sfw_goal_args ga{};
+  double vy_samp = 0.0;
+  int skip_zero = 1;
+  int64_t index_base = 0;
+  bool staged = false, launched = false;
+
+  // per-sample outputs + per-chunk table
+  dev_buf<int32_t> status;
+  dev_buf<double> base_cost, costs;
+  dev_buf<sfw_robot_step> rstep;
+  dev_buf<sfw_sel> partials, sel;
+  dev_buf<double> points;
+  dev_buf<int32_t> n_points;
+  size_t table_budget_bytes = size_t(2) << 30;  // K1->K2 robot-step table per chunk
+};
+
+namespace {
+
+int fail(sfw_handle h, int code, const std::string &msg) {
+  if (h) h->err = msg;
+  return code;
+}
+int hip_fail(sfw_handle h, hipError_t e, const char *what) {
+  return fail(h, SFW_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define SFW_HIP(h, call)                                   \
+  do {                                                     \
+    hipError_t e_ = (call);                                \
+    if (e_ != hipSuccess) return hip_fail((h), e_, #call); \
+  } while (0)
+
+int num_steps_of(const sfw_params &p) {
+  int n = static_cast<int>(p.sim_time / p.sim_granularity + 0.5);  // ref :519
+  return n == 0 ? 1 : n;                                           // ref :523-525
+}
+
+int check_params(sfw_handle h, const sfw_params *p) {
+  if (!p) return fail(h, SFW_ERR_INVALID_ARG, "params is NULL");
+  if (!(p->sim_granularity > 0) || !(p->sim_time >= 0))
+    return fail(h, SFW_ERR_INVALID_ARG, "sim_time/sim_granularity out of range");
+  if (p->precision != SFW_PRECISION_F64 && p->precision != SFW_PRECISION_F32)
+    return fail(h, SFW_ERR_INVALID_ARG, "unknown precision");
+  if (!(p->sfm_gamma > 0) || !(p->sfm_relaxation_time > 0) || !(p->sfm_force_sigma_obstacle > 0))
+    return fail(h, SFW_ERR_INVALID_ARG, "sfm gamma/relaxation_time/sigma must be > 0");
+  return SFW_OK;
+}
+
+// Fill the launch descriptor for samples [begin, begin+count).
+void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int64_t stride) {
+  std::memset(&L, 0, sizeof(L));
+  L.p = h->params;
+  L.S = num_steps_of(h->params);
+  L.dt = h->params.sim_time / L.S;  // ref :527
+  L.rs = h->rs;
+  L.ga = h->ga;
+  L.vy_samp = h->vy_samp;
+  L.skip_zero_sample = h->skip_zero;
+  L.linvels = h->linvels.p;
+  L.angvels = h->angvels.p;
+  L.nv = h->nv;
+  L.nw = h->nw;
+  L.chunk_begin = begin;
+  L.chunk_count = count;
+  L.cells = h->cells.p;
+  L.size_x = h->size_x;
+  L.size_y = h->size_y;
+  L.origin_x = h->origin_x;
+  L.origin_y = h->origin_y;
+  L.resolution = h->resolution;
+  L.footprint = h->footprint.p;
+  L.K = h->K;
+  L.agent_pos = h->agent_pos.p;
+  L.agent_vel = h->agent_vel.p;
+  L.agent_c = h->agent_c.p;
+  L.A = h->A;
+  L.obstacles = h->obstacles.p;
+  L.O = h->O;
+  L.status = h->status.p;
+  L.base_cost = h->base_cost.p;
+  L.costs = h->costs.p;
+  L.rstep = h->rstep.p;
+  L.rstep_stride = stride;
+  L.points = nullptr;
+  L.n_points = nullptr;
+}
+
+int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int32_t nv, const double *ang,
+                 int32_t nw, const sfw_goal_args *args, double vy_samp, int skip_zero, int64_t index_base) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  if (!rs || !lin || !ang || !args || nv <= 0 || nw <= 0)
+    return fail(h, SFW_ERR_INVALID_ARG, "grid_stage: null pointer or non-positive sample count");
+  if (!h->have_costmap) return fail(h, SFW_ERR_STATE, "grid_stage: no costmap set (sfw_set_costmap)");
+  SFW_HIP(h, hipSetDevice(h->device));
+  SFW_HIP(h, h->linvels.reserve(nv));
+  SFW_HIP(h, h->angvels.reserve(nw));
+  h->h_lin.assign(lin, lin + nv);
+  h->h_ang.assign(ang, ang + nw);
+  SFW_HIP(h, hipMemcpyAsync(h->linvels.p, h->h_lin.data(), sizeof(double) * nv, hipMemcpyHostToDevice,
+                            h->stream));
+  SFW_HIP(h, hipMemcpyAsync(h->angvels.p, h->h_ang.data(), sizeof(double) * nw, hipMemcpyHostToDevice,
+                            h->stream));
+  h->nv = nv;
+  h->nw = nw;
+  h->rs = *rs;
+  h->ga = *args;
+  h->vy_samp = vy_samp;
+  h->skip_zero = skip_zero;
+  h->index_base = index_base;
+  const int64_t T = static_cast<int64_t>(nv) * nw;
+  SFW_HIP(h, h->status.reserve(T));
+  SFW_HIP(h, h->base_cost.reserve(T));
+  SFW_HIP(h, h->costs.reserve(T));
+  SFW_HIP(h, h->partials.reserve(sfw_argmin_partials(T)));
+  SFW_HIP(h, h->sel.reserve(1));
+  // robot-step table: [S][chunk] records, chunk bounded by the table budget
+  const int S = num_steps_of(h->params);
+  int64_t chunk = static_cast<int64_t>(h->table_budget_bytes / (sizeof(sfw_robot_step) * S));
+  if (chunk < 1024) chunk = 1024;
+  if (chunk > T) chunk = T;
+  SFW_HIP(h, h->rstep.reserve(static_cast<size_t>(chunk) * S));
+  h->staged = true;
+  h->launched = false;
+  return SFW_OK;
+}
+
+int launch_common(sfw_handle h) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  if (!h->staged) return fail(h, SFW_ERR_STATE, "grid_launch before grid_stage");
+  SFW_HIP(h, hipSetDevice(h->device));
+  const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
+  const int S = num_steps_of(h->params);
+  // the table may have been sized under different params; re-derive the chunk
+  int64_t chunk = static_cast<int64_t>(h->rstep.cap / S);
+  if (chunk > T) chunk = T;
+  if (chunk < 1) return fail(h, SFW_ERR_STATE, "robot-step table too small (params changed after stage?)");
+  const size_t lds = sfw_social_lds_bytes(h->A, h->O, h->params.precision);
+  if (h->A > 0 && lds > 160 * 1024)
+    return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
+  SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  const bool single = chunk >= T;
+  for (int64_t b = 0; b < T; b += chunk) {
+    const int64_t n = (T - b < chunk) ? (T - b) : chunk;
+    sfw_launch L;
+    fill_launch(h, L, b, n, chunk);
+    SFW_HIP(h, sfw_launch_rollout(L, h->stream));
+    if (single) SFW_HIP(h, hipEventRecord(h->ev[1], h->stream));
+    SFW_HIP(h, sfw_launch_social(L, h->stream));
+  }
+  if (!single) SFW_HIP(h, hipEventRecord(h->ev[1], h->stream));  // K1/K2 interleaved: split not meaningful
+  SFW_HIP(h, hipEventRecord(h->ev[2], h->stream));
+  SFW_HIP(h, sfw_launch_argmin(h->costs.p, h->linvels.p, h->angvels.p, h->nw, T, h->index_base,
+                               h->partials.p, h->sel.p, h->stream));
+  SFW_HIP(h, hipEventRecord(h->ev[3], h->stream));
+  h->launched = true;
+  return SFW_OK;
+}
+
+void sel_to_best(sfw_handle h, const sfw_sel &s, sfw_best *best, sfw_best_key *key) {
+  const bool found = std::isfinite(s.cost);
+  if (best) {
+    best->n_valid = s.n_valid;
+    if (found) {
+      const int64_t local = -s.neg_index - h->index_base;
+      best->index = local;
+      best->cost = s.cost;
+      best->vx = h->h_lin[static_cast<size_t>(local / h->nw)];
+      best->vy = 0.0;
+      best->vtheta = h->h_ang[static_cast<size_t>(local % h->nw)];
+    } else {  // ref :456-468: stop the robot
+      best->index = -1;
+      best->cost = -1.0;
+      best->vx = best->vy = best->vtheta = 0.0;
+    }
+  }
+  if (key) {
+    key->cost = found ? s.cost : std::numeric_limits<double>::infinity();
+    key->neg_linvel = found ? s.neg_linvel : std::numeric_limits<double>::infinity();
+    key->abs_angvel = found ? s.abs_angvel : std::numeric_limits<double>::infinity();
+    key->neg_index = found ? static_cast<double>(s.neg_index) : std::numeric_limits<double>::infinity();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void sfw_params_default(sfw_params *p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  // ControllerParams defaults, reference sfw_planner.hpp:56-66
+  p->max_vel_x = 0.7;
+  p->sim_time = 1.0;
+  p->sim_granularity = 0.025;
+  p->robot_radius = 0.35f;
+  p->social_weight = 1.2;
+  p->costmap_weight = 2.0;
+  p->angle_weight = 0.7;
+  p->distance_weight = 1.0;
+  p->vel_weight = 1.0;
+  p->robot_goal_radius = 0.20;  // reference src/sfw_planner.cpp:608
+  // lightsfm sfm::Parameters defaults
+  p->sfm_force_factor_desired = 2.0;
+  p->sfm_force_factor_obstacle = 10.0;
+  p->sfm_force_sigma_obstacle = 0.2;
+  p->sfm_force_factor_social = 2.1;
+  p->sfm_lambda = 2.0;
+  p->sfm_gamma = 0.35;
+  p->sfm_n = 2.0;
+  p->sfm_n_prime = 3.0;
+  p->sfm_relaxation_time = 0.5;
+  p->precision = SFW_PRECISION_F64;
+}
+
+int sfw_abi_version(void) { return SFW_ABI_VERSION; }
+
+int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
+  if (!out) return SFW_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (int e = check_params(nullptr, params)) return e;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SFW_ERR_NO_DEVICE;
+  if (device < 0 || device >= count) return SFW_ERR_INVALID_ARG;
+  sfw_handle h = new (std::nothrow) sfw_planner_s();
+  if (!h) return SFW_ERR_HIP;
+  h->params = *params;
+  h->device = device;
+  if (const char *b = std::getenv("SFW_TABLE_BUDGET_MB")) {
+    long mb = std::atol(b);
+    if (mb > 0) h->table_budget_bytes = static_cast<size_t>(mb) << 20;
+  }
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
+  if (e != hipSuccess) {
+    sfw_destroy(h);
+    return SFW_ERR_HIP;
+  }
+  *out = h;
+  return SFW_OK;
+}
+
+int sfw_destroy(sfw_handle h) {
+  if (!h) return SFW_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->cells.release();
+  h->footprint.release();
+  h->agent_pos.release();
+  h->agent_vel.release();
+  h->obstacles.release();
+  h->agent_c.release();
+  h->linvels.release();
+  h->angvels.release();
+  h->status.release();
+  h->base_cost.release();
+  h->costs.release();
+  h->rstep.release();
+  h->partials.release();
+  h->sel.release();
+  h->points.release();
+  h->n_points.release();
+  for (auto &e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return SFW_OK;
+}
+
+int sfw_set_params(sfw_handle h, const sfw_params *params) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  if (int e = check_params(h, params)) return e;
+  h->params = *params;
+  return SFW_OK;
+}
+
+const char *sfw_last_error(sfw_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int sfw_set_costmap(sfw_handle h, const uint8_t *cells, uint32_t size_x, uint32_t size_y, double origin_x,
+                    double origin_y, double resolution) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  if (!cells || size_x == 0 || size_y == 0 || !(resolution > 0))
+    return fail(h, SFW_ERR_INVALID_ARG, "set_costmap: null cells, zero size or non-positive resolution");
+  SFW_HIP(h, hipSetDevice(h->device));
+  const size_t n = static_cast<size_t>(size_x) * size_y;
+  SFW_HIP(h, hipStreamSynchronize(h->stream));  // a previous launch may still read the old snapshot
+  SFW_HIP(h, h->cells.reserve(n));
+  SFW_HIP(h, hipMemcpyAsync(h->cells.p, cells, n, hipMemcpyHostToDevice, h->stream));
+  SFW_HIP(h, hipStreamSynchronize(h->stream));  // caller may free `cells` on return
+  h->size_x = size_x;
+  h->size_y = size_y;
+  h->origin_x = origin_x;
+  h->origin_y = origin_y;
+  h->resolution = resolution;
+  h->have_costmap = true;
+  return SFW_OK;
+}
+
+int sfw_set_footprint(sfw_handle h, const double *xy, int32_t K) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  if (K < 0 || (K > 0 && !xy)) return fail(h, SFW_ERR_INVALID_ARG, "set_footprint: bad arguments");
+  SFW_HIP(h, hipSetDevice(h->device));
+  SFW_HIP(h, hipStreamSynchronize(h->stream));
+  SFW_HIP(h, h->footprint.reserve(static_cast<size_t>(2) * (K > 0 ? K : 1)));
+  if (K > 0) {
+    SFW_HIP(h, hipMemcpyAsync(h->footprint.p, xy, sizeof(double) * 2 * K, hipMemcpyHostToDevice, h->stream));
+    SFW_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  h->K = K;
+  return SFW_OK;
+}
+
+int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const double *obstacles_xy, int32_t O) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  if (A < 0 || O < 0 || (A > 0 && !agents) || (O > 0 && !obstacles_xy))
+    return fail(h, SFW_ERR_INVALID_ARG, "set_agents: bad arguments");
+  for (int i = 0; i < A; ++i)
+    if (agents[i].group_id >= 0)
+      return fail(h, SFW_ERR_UNSUPPORTED, "set_agents: group forces (group_id >= 0) are not built yet");
+  SFW_HIP(h, hipSetDevice(h->device));
+  SFW_HIP(h, hipStreamSynchronize(h->stream));
+  std::vector<double> pos(2 * static_cast<size_t>(A > 0 ? A : 1)), vel(pos.size());
+  std::vector<sfw_agent_const> cst(static_cast<size_t>(A > 0 ? A : 1));
+  for (int i = 0; i < A; ++i) {
+    pos[2 * i] = agents[i].x;
+    pos[2 * i + 1] = agents[i].y;
+    vel[2 * i] = agents[i].vx;
+    vel[2 * i + 1] = agents[i].vy;
+    sfw_agent_const &c = cst[i];
+    c.goal_x = agents[i].goal_x;
+    c.goal_y = agents[i].goal_y;
+    c.goal_radius = agents[i].goal_radius;
+    c.desired_velocity = agents[i].desired_velocity;
+    c.radius = agents[i].radius;
+    c.id = agents[i].id;
+    c.has_goal = agents[i].has_goal ? 1 : 0;
+  }
+  SFW_HIP(h, h->agent_pos.reserve(pos.size()));
+  SFW_HIP(h, h->agent_vel.reserve(vel.size()));
+  SFW_HIP(h, h->agent_c.reserve(cst.size()));
+  SFW_HIP(h, h->obstacles.reserve(static_cast<size_t>(2) * (O > 0 ? O : 1)));
+  SFW_HIP(h, hipMemcpyAsync(h->agent_pos.p, pos.data(), sizeof(double) * pos.size(), hipMemcpyHostToDevice,
+                            h->stream));
+  SFW_HIP(h, hipMemcpyAsync(h->agent_vel.p, vel.data(), sizeof(double) * vel.size(), hipMemcpyHostToDevice,
+                            h->stream));
+  SFW_HIP(h, hipMemcpyAsync(h->agent_c.p, cst.data(), sizeof(sfw_agent_const) * cst.size(),
+                            hipMemcpyHostToDevice, h->stream));
+  if (O > 0)
+    SFW_HIP(h, hipMemcpyAsync(h->obstacles.p, obstacles_xy, sizeof(double) * 2 * O, hipMemcpyHostToDevice,
+                              h->stream));
+  SFW_HIP(h, hipStreamSynchronize(h->stream));
+  h->A = A;
+  h->O = O;
+  return SFW_OK;
+}
+
+int sfw_grid_stage(sfw_handle h, const sfw_robot_state *rs, const double *linvels, int32_t nv,
+                   const double *angvels, int32_t nw, const sfw_goal_args *args, int64_t index_base) {
+  return stage_common(h, rs, linvels, nv, angvels, nw, args, 0.0, 1, index_base);
+}
+
+int sfw_grid_launch(sfw_handle h) { return launch_common(h); }
+
+int sfw_grid_sync(sfw_handle h) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  SFW_HIP(h, hipSetDevice(h->device));
+  SFW_HIP(h, hipStreamSynchronize(h->stream));
+  return SFW_OK;
+}
+
+int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out, sfw_best_key *key_out) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  if (!h->launched) return fail(h, SFW_ERR_STATE, "grid_fetch before grid_launch");
+  SFW_HIP(h, hipSetDevice(h->device));
+  const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
+  sfw_sel s;
+  if (costs_out)
+    SFW_HIP(h, hipMemcpyAsync(costs_out, h->costs.p, sizeof(double) * T, hipMemcpyDeviceToHost, h->stream));
+  SFW_HIP(h, hipMemcpyAsync(&s, h->sel.p, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+  SFW_HIP(h, hipStreamSynchronize(h->stream));
+  sel_to_best(h, s, best_out, key_out);
+  return SFW_OK;
+}
+
+int sfw_score_grid(sfw_handle h, const sfw_robot_state *rs, const double *linvels, int32_t nv,
+                   const double *angvels, int32_t nw, const sfw_goal_args *args, double *costs_out,
+                   sfw_best *best_out) {
+  if (int e = sfw_grid_stage(h, rs, linvels, nv, angvels, nw, args, 0)) return e;
+  if (int e = sfw_grid_launch(h)) return e;
+  return sfw_grid_fetch(h, costs_out, best_out, nullptr);
+}
+
+int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp, double vy_samp, double vtheta_samp,
+                  const sfw_goal_args *args, double *cost_out, double *points_xyth, int32_t points_cap,
+                  int32_t *n_points) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  if (!cost_out) return fail(h, SFW_ERR_INVALID_ARG, "score_one: cost_out is NULL");
+  if (int e = stage_common(h, rs, &vx_samp, 1, &vtheta_samp, 1, args, vy_samp, 0, 0)) return e;
+  const int S = num_steps_of(h->params);
+  SFW_HIP(h, h->points.reserve(static_cast<size_t>(3) * S));
+  SFW_HIP(h, h->n_points.reserve(1));
+  sfw_launch L;
+  fill_launch(h, L, 0, 1, 1);
+  L.points = h->points.p;
+  L.n_points = h->n_points.p;
+  SFW_HIP(h, sfw_launch_rollout(L, h->stream));
+  SFW_HIP(h, sfw_launch_social(L, h->stream));
+  int32_t n = 0;
+  SFW_HIP(h, hipMemcpyAsync(cost_out, h->costs.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  SFW_HIP(h, hipMemcpyAsync(&n, h->n_points.p, sizeof(n), hipMemcpyDeviceToHost, h->stream));
+  SFW_HIP(h, hipStreamSynchronize(h->stream));
+  if (n_points) *n_points = n;
+  if (points_xyth && points_cap > 0 && n > 0) {
+    const int m = n < points_cap ? n : points_cap;
+    SFW_HIP(h, hipMemcpy(points_xyth, h->points.p, sizeof(double) * 3 * m, hipMemcpyDeviceToHost));
+  }
+  h->staged = false;  // score_one clobbers the staged grid
+  h->launched = false;
+  return SFW_OK;
+}
+
+int sfw_last_launch_ms(sfw_handle h, int32_t which, float *ms_out) {
+  if (!h || !ms_out) return SFW_ERR_INVALID_ARG;
+  if (!h->launched) return fail(h, SFW_ERR_STATE, "last_launch_ms before grid_launch");
+  SFW_HIP(h, hipSetDevice(h->device));
+  SFW_HIP(h, hipEventSynchronize(h->ev[3]));
+  int a = 0, b = 3;
+  switch (which) {
+    case 0: a = 0; b = 3; break;
+    case 1: a = 0; b = 1; break;
+    case 2: a = 1; b = 2; break;
+    case 3: a = 2; b = 3; break;
+    default: return fail(h, SFW_ERR_INVALID_ARG, "last_launch_ms: which must be 0..3");
+  }
+  SFW_HIP(h, hipEventElapsedTime(ms_out, h->ev[a], h->ev[b]));
+  return SFW_OK;
+}
+
+int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth, int32_t points_cap, int32_t *n_points) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  if (!h->staged) return fail(h, SFW_ERR_STATE, "grid_points before grid_stage");
+  const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
+  if (index < 0 || index >= T || !points_xyth || points_cap <= 0)
+    return fail(h, SFW_ERR_INVALID_ARG, "grid_points: bad index or buffer");
+  SFW_HIP(h, hipSetDevice(h->device));
+  const int S = num_steps_of(h->params);
+  SFW_HIP(h, h->points.reserve(static_cast<size_t>(3) * S));
+  SFW_HIP(h, h->n_points.reserve(1));
+  // Re-run K1 for that one sample into scratch outputs so the grid results stay intact.
+  dev_buf<int32_t> st;
+  dev_buf<double> bc, cs;
+  dev_buf<sfw_robot_step> tb;
+  SFW_HIP(h, st.reserve(T));
+  SFW_HIP(h, bc.reserve(T));
+  SFW_HIP(h, cs.reserve(T));
+  SFW_HIP(h, tb.reserve(S));
+  sfw_launch L;
+  fill_launch(h, L, index, 1, 1);
+  L.status = st.p;
+  L.base_cost = bc.p;
+  L.costs = cs.p;
+  L.rstep = tb.p;
+  L.skip_zero_sample = 0;
+  L.points = h->points.p;
+  L.n_points = h->n_points.p;
+  hipError_t e = sfw_launch_rollout(L, h->stream);
+  int32_t n = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&n, h->n_points.p, sizeof(n), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess && n > 0) {
+    const int m = n < points_cap ? n : points_cap;
+    e = hipMemcpy(points_xyth, h->points.p, sizeof(double) * 3 * m, hipMemcpyDeviceToHost);
+  }
+  st.release();
+  bc.release();
+  cs.release();
+  tb.release();
+  if (e != hipSuccess) return hip_fail(h, e, "grid_points");
+  if (n_points) *n_points = n;
+  return SFW_OK;
+}
+
+void *sfw_stream(sfw_handle h) { return h ? static_cast<void *>(h->stream) : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// sfw_device.h — internal contract between the C-ABI host code (sfw_capi.hip)
+// and the gfx950 kernels (sfw_kernels.hip).  Not part of the public ABI.
+#ifndef SFW_DEVICE_H_
+#define SFW_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sfw_hip.h"
+
+// Per-sample status written by the rollout kernel.
+enum : int32_t { SFW_ST_VALID = 0, SFW_ST_INVALID = 1, SFW_ST_SKIPPED = 2 };
+
+// Post-step robot agent state for one (step, sample): what the reference
+// writes into myagents[0] at src/sfw_planner.cpp:600-604 (position and the
+// robot-LOCAL velocity).  32 bytes, one coalesced line per 4 samples.
+struct __attribute__((aligned(32))) sfw_robot_step {
+  double x, y, vx, vy;
+};
+
+// Person constants shared by every sample (device copy, SoA-friendly AoS).
+struct __attribute__((aligned(16))) sfw_agent_const {
+  double goal_x, goal_y;
+  double goal_radius, desired_velocity;
+  double radius;
+  int32_t id, has_goal;
+};
+
+// Everything the kernels need that is uniform over a launch.
+struct sfw_launch {
+  // scoring parameters
+  sfw_params p;
+  int32_t S;        // num_steps
+  double dt;        // sim_time / S
+  // robot + goal
+  sfw_robot_state rs;
+  sfw_goal_args ga;
+  double vy_samp;   // 0.0 for the grid loop
+  int32_t skip_zero_sample;  // 1 for the grid loop (:349-352), 0 for score_one
+  // samples: sample t = chunk_begin + local index; iv = t / nw, iw = t % nw
+  const double *linvels;
+  const double *angvels;
+  int32_t nv, nw;
+  int64_t chunk_begin;  // first sample of this chunk
+  int64_t chunk_count;  // samples in this chunk
+  // costmap snapshot
+  const uint8_t *cells;
+  uint32_t size_x, size_y;
+  double origin_x, origin_y, resolution;
+  const double *footprint;  // K x (x,y)
+  int32_t K;
+  // agents (index 0 = robot) and shared obstacle points
+  const double *agent_pos;         // A x (x,y)
+  const double *agent_vel;         // A x (vx,vy)
+  const sfw_agent_const *agent_c;  // A
+  int32_t A;
+  const double *obstacles;         // O x (x,y)
+  int32_t O;
+  // per-sample outputs, indexed by GLOBAL sample index
+  int32_t *status;       // T
+  double *base_cost;     // T : vel + distance + angle + costmap terms (ref :663-666)
+  double *costs;         // T : final cost or sentinel
+  // per-chunk table, indexed [step][local sample]
+  sfw_robot_step *rstep;
+  int64_t rstep_stride;  // samples per step row
+  // optional Trajectory-points dump (x,y,theta per pre-step pose), one sample
+  double *points;        // nullable, 3*S doubles
+  int32_t *n_points;     // nullable
+};
+
+// Selection record (see sfw_best / sfw_best_key in the public header).
+struct sfw_sel {
+  double cost;       // +inf when nothing selectable
+  double neg_linvel;
+  double abs_angvel;
+  long long neg_index;  // -(global iteration index)
+  long long n_valid;
+};
+
+// Launchers (sfw_kernels.hip).  All enqueue on `stream` and return hipError_t.
+hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream);
+hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream);
+// Reduces costs[0..T) to one sfw_sel at *out (device memory).  partials must
+// hold >= sfw_argmin_partials(T) records.
+int64_t sfw_argmin_partials(int64_t T);
+hipError_t sfw_launch_argmin(const double *costs, const double *linvels, const double *angvels,
+                             int32_t nw, int64_t T, int64_t index_base, sfw_sel *partials,
+                             sfw_sel *out, hipStream_t stream);
+// Samples handled by one wave of the social kernel for A agents.
+int sfw_samples_per_wave(int A);
+size_t sfw_social_lds_bytes(int A, int O, int precision);
+
+#endif  // SFW_DEVICE_H_

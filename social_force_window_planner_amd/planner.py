@@ -1,0 +1,225 @@
+"""ctypes binding of the product C-ABI library (libsfw_hip.so, include/sfw_hip.h).
+
+This is plumbing for tests and bench.py; the C++ host mirror of the reference's
+SFWPlanner lives in host/.  There is no CPU fallback here: if the HIP library
+is missing or no GPU is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ._abi import (
+    EXPORTED_SYMBOLS,
+    SFW_ERR_NO_DEVICE,
+    SFW_OK,
+    SfwAgent,
+    SfwBest,
+    SfwBestKey,
+    SfwGoalArgs,
+    SfwParams,
+    SfwRobotState,
+    default_params,
+)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfw_hip.so")
+_lib = None
+
+
+class SfwError(RuntimeError):
+    def __init__(self, status, what, detail=""):
+        super().__init__(f"{what} failed: status {status}" + (f" ({detail})" if detail else ""))
+        self.status = status
+
+
+def build(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles on CPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in ("sfw_capi.hip", "sfw_kernels.hip", "sfw_device.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "sfw_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs)
+    if force or stale:
+        r = subprocess.run(["make", "-C", csrc, "all"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building libsfw_hip.so failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the scoring path)")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.sfw_params_default.argtypes = [C.POINTER(SfwParams)]
+        L.sfw_params_default.restype = None
+        L.sfw_abi_version.restype = C.c_int
+        L.sfw_create.argtypes = [C.POINTER(SfwParams), C.c_int, C.POINTER(vp)]
+        L.sfw_destroy.argtypes = [vp]
+        L.sfw_set_params.argtypes = [vp, C.POINTER(SfwParams)]
+        L.sfw_last_error.argtypes = [vp]
+        L.sfw_last_error.restype = C.c_char_p
+        L.sfw_set_costmap.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]
+        L.sfw_set_footprint.argtypes = [vp, vp, C.c_int32]
+        L.sfw_set_agents.argtypes = [vp, vp, C.c_int32, vp, C.c_int32]
+        L.sfw_score_grid.argtypes = [vp, C.POINTER(SfwRobotState), vp, C.c_int32, vp, C.c_int32,
+                                     C.POINTER(SfwGoalArgs), vp, C.POINTER(SfwBest)]
+        L.sfw_score_one.argtypes = [vp, C.POINTER(SfwRobotState), C.c_double, C.c_double, C.c_double,
+                                    C.POINTER(SfwGoalArgs), C.POINTER(C.c_double), vp, C.c_int32,
+                                    C.POINTER(C.c_int32)]
+        L.sfw_grid_stage.argtypes = [vp, C.POINTER(SfwRobotState), vp, C.c_int32, vp, C.c_int32,
+                                     C.POINTER(SfwGoalArgs), C.c_int64]
+        L.sfw_grid_launch.argtypes = [vp]
+        L.sfw_grid_sync.argtypes = [vp]
+        L.sfw_grid_fetch.argtypes = [vp, vp, C.POINTER(SfwBest), C.POINTER(SfwBestKey)]
+        L.sfw_last_launch_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
+        L.sfw_grid_points.argtypes = [vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32)]
+        L.sfw_stream.argtypes = [vp]
+        L.sfw_stream.restype = vp
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    L = lib()
+    return {name: hasattr(L, name) for name in EXPORTED_SYMBOLS}
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class HipScorer:
+    """The (v,w) grid scorer on one MI355X.  Method-for-method the same surface
+    as oracle.sfw_oracle.OracleScorer."""
+
+    def __init__(self, params: SfwParams | None = None, device: int = 0):
+        self.params = params if params is not None else default_params()
+        self._h = C.c_void_p()
+        rc = lib().sfw_create(C.byref(self.params), device, C.byref(self._h))
+        if rc == SFW_ERR_NO_DEVICE:
+            raise SfwError(rc, "sfw_create", "no HIP device visible; this library has no CPU fallback")
+        if rc != SFW_OK:
+            raise SfwError(rc, "sfw_create")
+        self._grid = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sfw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != SFW_OK:
+            raise SfwError(rc, what, (lib().sfw_last_error(self._h) or b"").decode())
+
+    # -- world state -------------------------------------------------------
+    def set_params(self, params):
+        self._check(lib().sfw_set_params(self._h, C.byref(params)), "sfw_set_params")
+        self.params = params
+
+    def set_costmap(self, cells, origin_x, origin_y, resolution):
+        cells = np.ascontiguousarray(cells, dtype=np.uint8)
+        sy, sx = cells.shape
+        self._check(lib().sfw_set_costmap(self._h, cells.ctypes.data, sx, sy, origin_x, origin_y, resolution),
+                    "sfw_set_costmap")
+
+    def set_footprint(self, xy):
+        xy = _f64(xy).reshape(-1, 2)
+        self._check(lib().sfw_set_footprint(self._h, xy.ctypes.data if len(xy) else None, len(xy)),
+                    "sfw_set_footprint")
+
+    def set_agents(self, agents, obstacles=None):
+        n = len(agents)
+        obs = _f64(obstacles if obstacles is not None else np.zeros((0, 2))).reshape(-1, 2)
+        self._check(lib().sfw_set_agents(self._h, C.addressof(agents) if n else None, n,
+                                         obs.ctypes.data if len(obs) else None, len(obs)), "sfw_set_agents")
+
+    def load_scene(self, scene):
+        self.set_costmap(scene.cells, scene.origin_x, scene.origin_y, scene.resolution)
+        self.set_footprint(scene.footprint)
+        self.set_agents(scene.agents, scene.obstacles)
+
+    # -- scoring -----------------------------------------------------------
+    def score_grid(self, robot_state, linvels, angvels, goal_args):
+        lin, ang = _f64(linvels), _f64(angvels)
+        rs, ga = SfwRobotState(*robot_state), SfwGoalArgs(*goal_args)
+        costs = np.empty(len(lin) * len(ang), dtype=np.float64)
+        best = SfwBest()
+        self._check(lib().sfw_score_grid(self._h, C.byref(rs), lin.ctypes.data, len(lin), ang.ctypes.data,
+                                         len(ang), C.byref(ga), costs.ctypes.data, C.byref(best)),
+                    "sfw_score_grid")
+        self._grid = (len(lin), len(ang))
+        return costs, best.as_dict()
+
+    def score_one(self, robot_state, vx_samp, vy_samp, vth_samp, goal_args, points_cap=4096):
+        rs, ga = SfwRobotState(*robot_state), SfwGoalArgs(*goal_args)
+        cost = C.c_double()
+        pts = np.zeros((points_cap, 3), dtype=np.float64)
+        n = C.c_int32()
+        self._check(lib().sfw_score_one(self._h, C.byref(rs), vx_samp, vy_samp, vth_samp, C.byref(ga),
+                                        C.byref(cost), pts.ctypes.data, points_cap, C.byref(n)),
+                    "sfw_score_one")
+        self._grid = None
+        return cost.value, pts[: min(n.value, points_cap)].copy()
+
+    # -- device-resident pipeline -----------------------------------------
+    def stage(self, robot_state, linvels, angvels, goal_args, index_base=0):
+        lin, ang = _f64(linvels), _f64(angvels)
+        rs, ga = SfwRobotState(*robot_state), SfwGoalArgs(*goal_args)
+        self._check(lib().sfw_grid_stage(self._h, C.byref(rs), lin.ctypes.data, len(lin), ang.ctypes.data,
+                                         len(ang), C.byref(ga), index_base), "sfw_grid_stage")
+        self._grid = (len(lin), len(ang))
+
+    def launch(self):
+        self._check(lib().sfw_grid_launch(self._h), "sfw_grid_launch")
+
+    def sync(self):
+        self._check(lib().sfw_grid_sync(self._h), "sfw_grid_sync")
+
+    def fetch(self, want_costs=True):
+        nv, nw = self._grid
+        costs = np.empty(nv * nw, dtype=np.float64) if want_costs else None
+        best, key = SfwBest(), SfwBestKey()
+        self._check(lib().sfw_grid_fetch(self._h, costs.ctypes.data if want_costs else None, C.byref(best),
+                                         C.byref(key)), "sfw_grid_fetch")
+        return costs, best.as_dict(), key.as_tuple()
+
+    def last_launch_ms(self, which=0):
+        ms = C.c_float()
+        self._check(lib().sfw_last_launch_ms(self._h, which, C.byref(ms)), "sfw_last_launch_ms")
+        return ms.value
+
+    def grid_points(self, index, points_cap=4096):
+        pts = np.zeros((points_cap, 3), dtype=np.float64)
+        n = C.c_int32()
+        self._check(lib().sfw_grid_points(self._h, index, pts.ctypes.data, points_cap, C.byref(n)),
+                    "sfw_grid_points")
+        return pts[: min(n.value, points_cap)].copy()
+
+
+def select_across_ranks(keys):
+    """Lexicographic minimum over per-rank sfw_best_key tuples: the reference's
+    selection order (cost up, linvel down, |angvel| up, iteration index down).
+    Returns (rank, key) or (None, None) when no rank holds a selectable sample."""
+    best_rank, best_key = None, None
+    for r, k in enumerate(keys):
+        k = tuple(float(x) for x in k)
+        if not np.isfinite(k[0]):
+            continue
+        if best_key is None or k < best_key:
+            best_rank, best_key = r, k
+    return best_rank, best_key
