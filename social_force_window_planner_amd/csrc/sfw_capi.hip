@@ -5,6 +5,7 @@
 
 #include "sfw_device.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -71,6 +72,8 @@ struct sfw_planner_s {
   dev_buf<int32_t> status;
   dev_buf<double> base_cost, costs;
   dev_buf<sfw_robot_step> rstep;
+  dev_buf<sfw_pose_frame> frame;
+  dev_buf<int16_t> fcode;
   dev_buf<sfw_sel> partials, sel;
   dev_buf<double> points;
   dev_buf<int32_t> n_points;
@@ -142,6 +145,8 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.base_cost = h->base_cost.p;
   L.costs = h->costs.p;
   L.rstep = h->rstep.p;
+  L.frame = h->frame.p;
+  L.fcode = h->fcode.p;
   L.rstep_stride = stride;
   L.points = nullptr;
   L.n_points = nullptr;
@@ -177,10 +182,13 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   SFW_HIP(h, h->sel.reserve(1));
   // robot-step table: [S][chunk] records, chunk bounded by the table budget
   const int S = num_steps_of(h->params);
-  int64_t chunk = static_cast<int64_t>(h->table_budget_bytes / (sizeof(sfw_robot_step) * S));
+  int64_t chunk = static_cast<int64_t>(
+      h->table_budget_bytes / ((sizeof(sfw_robot_step) + sizeof(sfw_pose_frame) + sizeof(int16_t)) * S));
   if (chunk < 1024) chunk = 1024;
   if (chunk > T) chunk = T;
   SFW_HIP(h, h->rstep.reserve(static_cast<size_t>(chunk) * S));
+  SFW_HIP(h, h->frame.reserve(static_cast<size_t>(chunk) * S));
+  SFW_HIP(h, h->fcode.reserve(static_cast<size_t>(chunk) * S));
   h->staged = true;
   h->launched = false;
   return SFW_OK;
@@ -193,7 +201,7 @@ int launch_common(sfw_handle h) {
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
   const int S = num_steps_of(h->params);
   // the table may have been sized under different params; re-derive the chunk
-  int64_t chunk = static_cast<int64_t>(h->rstep.cap / S);
+  int64_t chunk = static_cast<int64_t>(std::min(h->rstep.cap, std::min(h->frame.cap, h->fcode.cap)) / S);
   if (chunk > T) chunk = T;
   if (chunk < 1) return fail(h, SFW_ERR_STATE, "robot-step table too small (params changed after stage?)");
   const size_t lds = sfw_social_lds_bytes(h->A, h->O, h->params.precision);
@@ -318,6 +326,8 @@ int sfw_destroy(sfw_handle h) {
   h->base_cost.release();
   h->costs.release();
   h->rstep.release();
+  h->frame.release();
+  h->fcode.release();
   h->partials.release();
   h->sel.release();
   h->points.release();
@@ -512,16 +522,22 @@ int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth, int32_t po
   dev_buf<int32_t> st;
   dev_buf<double> bc, cs;
   dev_buf<sfw_robot_step> tb;
+  dev_buf<sfw_pose_frame> fr;
+  dev_buf<int16_t> fco;
   SFW_HIP(h, st.reserve(T));
   SFW_HIP(h, bc.reserve(T));
   SFW_HIP(h, cs.reserve(T));
   SFW_HIP(h, tb.reserve(S));
+  SFW_HIP(h, fr.reserve(S));
+  SFW_HIP(h, fco.reserve(S));
   sfw_launch L;
   fill_launch(h, L, index, 1, 1);
   L.status = st.p;
   L.base_cost = bc.p;
   L.costs = cs.p;
   L.rstep = tb.p;
+  L.frame = fr.p;
+  L.fcode = fco.p;
   L.skip_zero_sample = 0;
   L.points = h->points.p;
   L.n_points = h->n_points.p;
@@ -537,6 +553,8 @@ int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth, int32_t po
   bc.release();
   cs.release();
   tb.release();
+  fr.release();
+  fco.release();
   if (e != hipSuccess) return hip_fail(h, e, "grid_points");
   if (n_points) *n_points = n;
   return SFW_OK;

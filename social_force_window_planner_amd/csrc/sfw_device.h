@@ -18,6 +18,11 @@ struct __attribute__((aligned(32))) sfw_robot_step {
   double x, y, vx, vy;
 };
 
+// Pre-step footprint frame of one (step, sample): position and cos/sin(theta).
+struct __attribute__((aligned(32))) sfw_pose_frame {
+  double x, y, c, s;
+};
+
 // Person constants shared by every sample (device copy, SoA-friendly AoS).
 struct __attribute__((aligned(16))) sfw_agent_const {
   double goal_x, goal_y;
@@ -62,6 +67,8 @@ struct sfw_launch {
   double *costs;         // T : final cost or sentinel
   // per-chunk table, indexed [step][local sample]
   sfw_robot_step *rstep;
+  sfw_pose_frame *frame;
+  int16_t *fcode;        // footprint cost per (step, sample): -3,-2,-1 or 0..253
   int64_t rstep_stride;  // samples per step row
   // optional Trajectory-points dump (x,y,theta per pre-step pose), one sample
   double *points;        // nullable, 3*S doubles

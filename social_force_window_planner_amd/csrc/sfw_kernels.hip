@@ -2,7 +2,8 @@
 // social-force scoring path.  wave = 64 lanes everywhere.
 //
 //   K1  sfw_rollout_kernel   one THREAD per (v,w) sample: accel-limited unicycle
-//                            rollout, per-step costmap legality + footprint cost
+//       sfw_footprint_kernel rollout (K1a); one thread per (step, sample):
+//       sfw_costmap_scan_..  footprint legality + cost (K1b); in-order scan (K1c)
 //                            (reference src/sfw_planner.cpp:540-588, :643-667;
 //                            world_model.hpp:45-75; src/costmap_model.cpp:21-121;
 //                            line_iterator.hpp:39-97).  The robot's motion does
@@ -128,7 +129,10 @@ __device__ __forceinline__ float normalize_angle_f(float val, float mn, float mx
   return mx - fmodf(mn - val, mx - mn);
 }
 
-__global__ void __launch_bounds__(256) sfw_rollout_kernel(const sfw_launch L) {
+// K1a: sequential pose integration, one thread per sample.  Writes the
+// pre-step footprint frame (x_i, y_i, cos th_i, sin th_i) and the post-step robot
+// agent state for every step, plus the pedestrian-independent cost terms.
+__global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
   const int64_t local = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (local >= L.chunk_count) return;
   const int64_t t = L.chunk_begin + local;
@@ -139,28 +143,22 @@ __global__ void __launch_bounds__(256) sfw_rollout_kernel(const sfw_launch L) {
     L.costs[t] = SFW_COST_SKIPPED;
     return;
   }
+  L.status[t] = SFW_ST_VALID;  // K1c downgrades it if a step is illegal
   double x_i = L.rs.x, y_i = L.rs.y, th_i = L.rs.theta;
   double vx_i = L.rs.vx, vy_i = L.rs.vy, vth_i = L.rs.vtheta;
   const int S = L.S;
   const double dt = L.dt;
-  double cm = 0.0;
-  bool ok = true;
-  int n_pts = 0;
   for (int i = 0; i < S; ++i) {
     double s, c;
     sincos(th_i, &s, &c);
-    const double fc = footprint_cost(L, x_i, y_i, c, s);  // includes the ref :545 map check
-    if (fc >= 254.0 || fc < 0) {                          // ref :555, :565
-      ok = false;
-      break;
-    }
-    cm += fc / 255.0;                                     // ref :575
+    sfw_pose_frame f;
+    f.x = x_i; f.y = y_i; f.c = c; f.s = s;
+    L.frame[static_cast<int64_t>(i) * L.rstep_stride + local] = f;
     if (L.points) {                                       // ref :578
-      L.points[3 * n_pts] = x_i;
-      L.points[3 * n_pts + 1] = y_i;
-      L.points[3 * n_pts + 2] = th_i;
+      L.points[3 * i] = x_i;
+      L.points[3 * i + 1] = y_i;
+      L.points[3 * i + 2] = th_i;
     }
-    ++n_pts;
     vx_i = new_velocity(vx_samp, vx_i, L.ga.acc_x, dt);   // ref :581-583
     vy_i = new_velocity(vy_samp, vy_i, L.ga.acc_y, dt);
     vth_i = new_velocity(vth_samp, vth_i, L.ga.acc_theta, dt);
@@ -175,23 +173,54 @@ __global__ void __launch_bounds__(256) sfw_rollout_kernel(const sfw_launch L) {
     r.x = x_i; r.y = y_i; r.vx = vx_i; r.vy = vy_i;
     L.rstep[static_cast<int64_t>(i) * L.rstep_stride + local] = r;
   }
-  if (L.n_points) *L.n_points = n_pts;
-  if (!ok) {
-    L.status[t] = SFW_ST_INVALID;
-    L.costs[t] = SFW_COST_INVALID;
-    return;
-  }
-  // ref :643-667; the social term is added by K2 (left-to-right sum order kept)
+  // ref :643-666 without the costmap and social terms (left-to-right sum order kept)
   const double dx = L.ga.wpx - x_i, dy = L.ga.wpy - y_i;
   const double d = dx * dx + dy * dy;
   double ang = atan2(dy, dx) - th_i;
   ang = normalize_angle_f(static_cast<float>(ang), static_cast<float>(-M_PI), static_cast<float>(M_PI));
   ang = fabs(ang) / M_PI;
   const double vel = fabs(L.p.max_vel_x - vx_i) / L.p.max_vel_x;
+  L.base_cost[t] = L.p.vel_weight * vel + L.p.distance_weight * d + L.p.angle_weight * ang;
+}
+
+// K1b: footprint legality/cost of one pose, one thread per (step, sample).
+// Independent across steps once the poses are known, so the S*T checks run in
+// parallel instead of serially inside the rollout.
+__global__ void __launch_bounds__(256) sfw_footprint_kernel(const sfw_launch L) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t n = L.chunk_count;
+  if (idx >= n * L.S) return;
+  const int64_t step = idx / n, local = idx - step * n;
+  if (L.status[L.chunk_begin + local] == SFW_ST_SKIPPED) return;
+  const sfw_pose_frame f = L.frame[step * L.rstep_stride + local];
+  const double fc = footprint_cost(L, f.x, f.y, f.c, f.s);  // includes the ref :545 map check
+  L.fcode[step * L.rstep_stride + local] = static_cast<int16_t>(fc);
+}
+
+// K1c: in-order scan of the per-step footprint costs, one thread per sample:
+// first illegal step rejects the trajectory (ref :555-573), otherwise
+// costmap_cost accumulates in step order (ref :575, :656).
+__global__ void __launch_bounds__(256) sfw_costmap_scan_kernel(const sfw_launch L) {
+  const int64_t local = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (local >= L.chunk_count) return;
+  const int64_t t = L.chunk_begin + local;
+  if (L.status[t] == SFW_ST_SKIPPED) return;
+  const int S = L.S;
+  double cm = 0.0;
+  int n_ok = 0;
+  for (; n_ok < S; ++n_ok) {
+    const double fc = static_cast<double>(L.fcode[static_cast<int64_t>(n_ok) * L.rstep_stride + local]);
+    if (fc >= 254.0 || fc < 0) break;
+    cm += fc / 255.0;
+  }
+  if (L.n_points) *L.n_points = n_ok;
+  if (n_ok < S) {
+    L.status[t] = SFW_ST_INVALID;
+    L.costs[t] = SFW_COST_INVALID;
+    return;
+  }
   cm = cm / S;
-  const double base = L.p.vel_weight * vel + L.p.distance_weight * d + L.p.angle_weight * ang +
-                      L.p.costmap_weight * cm;
-  L.status[t] = SFW_ST_VALID;
+  const double base = L.base_cost[t] + L.p.costmap_weight * cm;
   L.base_cost[t] = base;
   // No agent vector at all: social work is identically 0 and K2 is not launched.
   if (L.A == 0) L.costs[t] = base + L.p.social_weight * 0.0;
@@ -645,9 +674,22 @@ size_t sfw_social_lds_bytes(int A, int O, int precision) {
 
 hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream) {
   if (L.chunk_count <= 0) return hipSuccess;
-  const int block = 256;
-  const unsigned grid = static_cast<unsigned>((L.chunk_count + block - 1) / block);
-  hipLaunchKernelGGL(sfw_rollout_kernel, dim3(grid), dim3(block), 0, stream, L);
+  {
+    const int block = 64;  // latency-bound serial rollout: spread the waves over all CUs
+    const unsigned grid = static_cast<unsigned>((L.chunk_count + block - 1) / block);
+    hipLaunchKernelGGL(sfw_rollout_kernel, dim3(grid), dim3(block), 0, stream, L);
+  }
+  {
+    const int block = 256;
+    const int64_t n = L.chunk_count * L.S;
+    const unsigned grid = static_cast<unsigned>((n + block - 1) / block);
+    hipLaunchKernelGGL(sfw_footprint_kernel, dim3(grid), dim3(block), 0, stream, L);
+  }
+  {
+    const int block = 256;
+    const unsigned grid = static_cast<unsigned>((L.chunk_count + block - 1) / block);
+    hipLaunchKernelGGL(sfw_costmap_scan_kernel, dim3(grid), dim3(block), 0, stream, L);
+  }
   return hipGetLastError();
 }
 
