@@ -397,6 +397,130 @@ static void select_best(const double *lin, int nv, const double *ang, int nw,
   else { out->index = -1; out->cost = -1.0; out->vx = out->vy = out->vtheta = 0.0; }
 }
 
+
+// ---------------------------------------------------------------------------
+// findBestAction state machine around the grid loop.
+// ref: src/sfw_planner.cpp:117-334, :426-468 (findBestAction), :853-892
+// (updatePlan), :894-902 (isGoalReached / resetGoal).
+// ---------------------------------------------------------------------------
+struct CtrlParams {  // numeric ControllerParams, ref sfw_planner.hpp:186-226
+  double max_vel_x, min_vel_x, max_vel_th, min_vel_th, max_trans_acc, max_rot_acc, min_in_place_vel_th;
+  double yaw_goal_tolerance, xy_goal_tolerance, wp_tolerance;
+  double sim_time, sim_granularity;
+  double robot_radius;
+  double social_weight, costmap_weight, angle_weight, distance_weight, vel_weight;
+  int32_t is_circular, precision;
+};
+struct PlanPose { double x, y, yaw; };
+enum Branch { kNotRunning = 0, kGoalReached, kRotateInPlace, kRotateBlocked, kApproach, kGrid, kGridFailed };
+
+struct Planner {
+  World *w = nullptr;
+  CtrlParams c{};
+  std::vector<double> lin, ang;
+  std::vector<PlanPose> plan;
+  int wp_index = -1;
+  bool running = false, new_plan = false, goal_reached = false;
+  double goal_x = 0, goal_y = 0, goal_t = 0;
+  std::vector<double> last_costs;
+  int last_branch = kNotRunning;
+
+  void sync_params() {
+    w->p.max_vel_x = c.max_vel_x;
+    w->p.sim_time = c.sim_time;
+    w->p.sim_granularity = c.sim_granularity;
+    w->p.robot_radius = (float)c.robot_radius;
+    w->p.social_weight = c.social_weight;
+    w->p.costmap_weight = c.costmap_weight;
+    w->p.angle_weight = c.angle_weight;
+    w->p.distance_weight = c.distance_weight;
+    w->p.vel_weight = c.vel_weight;
+  }
+
+  void update_plan(const PlanPose *poses, int n) {  // ref :853-892
+    goal_reached = false;
+    plan.assign(poses, poses + n);
+    if (plan.empty()) { running = false; wp_index = -1; return; }
+    wp_index = 0; running = true; new_plan = true;
+    goal_x = plan.back().x; goal_y = plan.back().y; goal_t = plan.back().yaw;
+  }
+
+  // returns findBestAction's bool; cmd = (vx, vy, vtheta)
+  bool find_best_action(const double pose[3], const double vel[3], double cmd[3]) {
+    sync_params();
+    goal_reached = false;
+    double vx, vy = 0.0, vt;
+    if (!running) { last_branch = kNotRunning; cmd[0] = cmd[1] = cmd[2] = 0.0; return true; }  // ref :131-142
+    const float rx = (float)pose[0], ry = (float)pose[1], rt = (float)pose[2];             // ref :145-152
+    const float rvx = (float)vel[0], rvy = (float)vel[1], rvt = (float)vel[2];
+    const double dist_goal_sq = (rx - goal_x) * (rx - goal_x) + (ry - goal_y) * (ry - goal_y);
+    if (dist_goal_sq < c.xy_goal_tolerance * c.xy_goal_tolerance) {                         // ref :176-233
+      vx = 0.0;
+      if (std::fabs(goal_t - rt) < c.yaw_goal_tolerance) {
+        vt = 0.0; running = false; goal_reached = true; last_branch = kGoalReached;
+      } else {
+        float ad = (float)(goal_t - rt);
+        ad = normalize_angle_f(ad, (float)-M_PI, (float)M_PI);
+        vt = ad > 0.0f ? c.min_in_place_vel_th : -c.min_in_place_vel_th;
+        last_branch = kRotateInPlace;
+        if (!c.is_circular) {
+          double sc = score_trajectory(*w, rx, ry, rt, rvx, rvy, rvt, vx, vy, vt, c.max_trans_acc, 0.0,
+                                       c.max_rot_acc, 0.0, 0.0, nullptr);
+          if (sc < 0.0) { last_branch = kRotateBlocked; cmd[0] = vx; cmd[1] = vy; cmd[2] = vt; return false; }
+        }
+      }
+      cmd[0] = vx; cmd[1] = vy; cmd[2] = vt;
+      return true;
+    }
+    if (new_plan) {                                                                          // ref :236-255
+      new_plan = false;
+      double min_dist = 9999.0;
+      wp_index = 0;
+      for (int i = (int)plan.size() - 1; i >= 0; --i) {
+        const double dsq = (rx - plan[i].x) * (rx - plan[i].x) + (ry - plan[i].y) * (ry - plan[i].y);
+        if (dsq < c.wp_tolerance * c.wp_tolerance) { wp_index = i; break; }
+        else if (dsq < min_dist) { min_dist = dsq; wp_index = i; }
+      }
+    }
+    double wpx = plan[wp_index].x, wpy = plan[wp_index].y;                                   // ref :258-271
+    double dsw = (rx - wpx) * (rx - wpx) + (ry - wpy) * (ry - wpy);
+    while (dsw < c.wp_tolerance * c.wp_tolerance && wp_index < (int)plan.size() - 1) {
+      ++wp_index;
+      wpx = plan[wp_index].x; wpy = plan[wp_index].y;
+      dsw = (rx - wpx) * (rx - wpx) + (ry - wpy) * (ry - wpy);
+    }
+    const double dx = (wpx - rx) * std::cos(rt) + (wpy - ry) * std::sin(rt);                 // ref :274-276
+    const double dy = -(wpx - rx) * std::sin(rt) + (wpy - ry) * std::cos(rt);
+    const double dth = std::atan2(dy, dx);
+    const double dist_thres = 1.5;                                                           // ref :282-334
+    if (dist_goal_sq < dist_thres * dist_thres) {
+      vx = c.min_vel_x + (c.max_vel_x - c.min_vel_x) * (std::sqrt(dist_goal_sq) / dist_thres);
+      vy = 0.0;
+      vt = c.min_vel_th + (c.max_vel_th - c.min_vel_th) * std::fabs(dth) / M_PI;
+      if (dth < 0.0) vt *= -1;
+      double sc = score_trajectory(*w, rx, ry, rt, rvx, rvy, rvt, vx, vy, vt, c.max_trans_acc, 0.0,
+                                   c.max_rot_acc, wpx, wpy, nullptr);
+      if (sc != -1) { last_branch = kApproach; cmd[0] = vx; cmd[1] = vy; cmd[2] = vt; return true; }
+    }
+    // the grid loop, ref :338-417
+    const int nv = (int)lin.size(), nw = (int)ang.size();
+    last_costs.assign((size_t)nv * nw, SFW_COST_INVALID);
+    for (int iv = 0; iv < nv; ++iv)
+      for (int iw = 0; iw < nw; ++iw) {
+        const size_t i = (size_t)iv * nw + iw;
+        if (lin[iv] == 0.0 && ang[iw] == 0.0) { last_costs[i] = SFW_COST_SKIPPED; continue; }
+        last_costs[i] = score_trajectory(*w, rx, ry, rt, rvx, rvy, rvt, lin[iv], 0.0, ang[iw],
+                                         c.max_trans_acc, 0.0, c.max_rot_acc, wpx, wpy, nullptr);
+      }
+    sfw_best b;
+    select_best(lin.data(), nv, ang.data(), nw, last_costs.data(), &b);
+    if (b.index >= 0) { last_branch = kGrid; cmd[0] = b.vx; cmd[1] = 0.0; cmd[2] = b.vtheta; return true; }
+    last_branch = kGridFailed;                                                               // ref :456-468
+    cmd[0] = cmd[1] = cmd[2] = 0.0;
+    return false;
+  }
+};
+
 }  // namespace sfwo
 
 // ===========================================================================
@@ -538,5 +662,51 @@ int sfwo_max_threads(void) {
 #else
   return 1;
 #endif
+}
+
+// ---- state machine ---------------------------------
+void *sfwo_planner_create(void *world, const sfwo::CtrlParams *c) {
+  sfwo::Planner *pl = new sfwo::Planner();
+  pl->w = static_cast<World *>(world);
+  pl->c = *c;
+  // sample sets built once from the creation-time limits, ref :64-85
+  const int n_lin = 4, n_ang = 4;
+  const double ls = c->max_vel_x / n_lin, as = c->max_vel_th / n_ang;
+  for (int i = 0; i <= n_lin; ++i) pl->lin.push_back(i * ls);
+  pl->ang.push_back(0.0);
+  for (int i = 1; i <= n_ang; ++i) { pl->ang.push_back(i * as); pl->ang.push_back(i * (-as)); }
+  return pl;
+}
+void sfwo_planner_destroy(void *p) { delete static_cast<sfwo::Planner *>(p); }
+void sfwo_planner_set_params(void *p, const sfwo::CtrlParams *c) { static_cast<sfwo::Planner *>(p)->c = *c; }
+void sfwo_planner_set_sample_sets(void *p, const double *lin, int32_t nv, const double *ang, int32_t nw) {
+  sfwo::Planner *pl = static_cast<sfwo::Planner *>(p);
+  pl->lin.assign(lin, lin + nv);
+  pl->ang.assign(ang, ang + nw);
+}
+void sfwo_planner_update_plan(void *p, const double *xyyaw, int32_t n) {
+  std::vector<sfwo::PlanPose> v((size_t)n);
+  for (int i = 0; i < n; ++i) v[i] = {xyyaw[3 * i], xyyaw[3 * i + 1], xyyaw[3 * i + 2]};
+  static_cast<sfwo::Planner *>(p)->update_plan(v.data(), n);
+}
+int sfwo_planner_find_best_action(void *p, const double *pose, const double *vel, double *cmd,
+                                  int32_t *found, int32_t *branch) {
+  sfwo::Planner *pl = static_cast<sfwo::Planner *>(p);
+  *found = pl->find_best_action(pose, vel, cmd) ? 1 : 0;
+  *branch = pl->last_branch;
+  return SFW_OK;
+}
+int sfwo_planner_is_goal_reached(void *p) {  // ref :894-900, one-shot
+  sfwo::Planner *pl = static_cast<sfwo::Planner *>(p);
+  if (pl->goal_reached) { pl->goal_reached = false; return 1; }
+  return 0;
+}
+int sfwo_planner_wp_index(void *p) { return static_cast<sfwo::Planner *>(p)->wp_index; }
+int sfwo_planner_running(void *p) { return static_cast<sfwo::Planner *>(p)->running ? 1 : 0; }
+int64_t sfwo_planner_last_costs(void *p, double *out, int64_t cap) {
+  const std::vector<double> &c = static_cast<sfwo::Planner *>(p)->last_costs;
+  const int64_t n = (int64_t)c.size();
+  if (out) std::memcpy(out, c.data(), sizeof(double) * (size_t)std::min(n, cap));
+  return n;
 }
 }  // extern "C"

@@ -181,3 +181,89 @@ def pair_force(params, me: SfwAgent, other: SfwAgent):
     out = np.zeros(2, dtype=np.float64)
     lib().sfwo_pair_force(C.byref(params), C.byref(me), C.byref(other), out.ctypes.data)
     return out
+
+
+class OraclePlanner:
+    """CPU restatement of findBestAction/updatePlan/isGoalReached around an
+    OracleScorer (reference src/sfw_planner.cpp:117-468, :853-902).  Same
+    surface as social_force_window_planner_amd.host.HostPlanner."""
+
+    def __init__(self, ctrl, scene):
+        from social_force_window_planner_amd._abi import CtrlParams, default_ctrl_params
+
+        L = lib()
+        L.sfwo_planner_create.argtypes = [C.c_void_p, C.POINTER(CtrlParams)]
+        L.sfwo_planner_create.restype = C.c_void_p
+        L.sfwo_planner_destroy.argtypes = [C.c_void_p]
+        L.sfwo_planner_destroy.restype = None
+        L.sfwo_planner_set_params.argtypes = [C.c_void_p, C.POINTER(CtrlParams)]
+        L.sfwo_planner_set_params.restype = None
+        L.sfwo_planner_set_sample_sets.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.sfwo_planner_set_sample_sets.restype = None
+        L.sfwo_planner_update_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.sfwo_planner_update_plan.restype = None
+        L.sfwo_planner_find_best_action.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.sfwo_planner_is_goal_reached.argtypes = [C.c_void_p]
+        L.sfwo_planner_wp_index.argtypes = [C.c_void_p]
+        L.sfwo_planner_running.argtypes = [C.c_void_p]
+        L.sfwo_planner_last_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.sfwo_planner_last_costs.restype = C.c_int64
+        self.ctrl = ctrl if ctrl is not None else default_ctrl_params()
+        self.scorer = OracleScorer(default_params())
+        self.scorer.load_scene(scene)
+        self._p = C.c_void_p(L.sfwo_planner_create(self.scorer._h, C.byref(self.ctrl)))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            lib().sfwo_planner_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, ctrl):
+        self.ctrl = ctrl
+        lib().sfwo_planner_set_params(self._p, C.byref(ctrl))
+
+    def set_agents(self, agents, obstacles=None):
+        self.scorer.set_agents(agents, obstacles)
+
+    def set_costmap(self, cells, ox, oy, res):
+        self.scorer.set_costmap(cells, ox, oy, res)
+
+    def set_sample_sets(self, lin, ang):
+        lin, ang = _f64(lin), _f64(ang)
+        lib().sfwo_planner_set_sample_sets(self._p, lin.ctypes.data, len(lin), ang.ctypes.data, len(ang))
+
+    def update_plan(self, xyyaw):
+        p = _f64(xyyaw).reshape(-1, 3)
+        lib().sfwo_planner_update_plan(self._p, p.ctypes.data if len(p) else None, len(p))
+
+    def find_best_action(self, pose, vel):
+        pose, vel = _f64(pose), _f64(vel)
+        cmd = np.zeros(3, dtype=np.float64)
+        found, branch = C.c_int32(), C.c_int32()
+        lib().sfwo_planner_find_best_action(self._p, pose.ctypes.data, vel.ctypes.data, cmd.ctypes.data,
+                                            C.byref(found), C.byref(branch))
+        return bool(found.value), cmd, branch.value
+
+    def is_goal_reached(self):
+        return bool(lib().sfwo_planner_is_goal_reached(self._p))
+
+    @property
+    def wp_index(self):
+        return lib().sfwo_planner_wp_index(self._p)
+
+    @property
+    def running(self):
+        return bool(lib().sfwo_planner_running(self._p))
+
+    def last_costs(self):
+        n = lib().sfwo_planner_last_costs(self._p, None, 0)
+        out = np.zeros(n, dtype=np.float64)
+        lib().sfwo_planner_last_costs(self._p, out.ctypes.data, n)
+        return out

@@ -145,3 +145,38 @@ EXPORTED_SYMBOLS = (
     "sfw_grid_points",
     "sfw_stream",
 )
+
+
+class CtrlParams(C.Structure):
+    """Numeric ControllerParams (reference sfw_planner.hpp:186-226), the layout of
+    sfwh_params in host/sfw_host_capi.cpp."""
+
+    _fields_ = [(n, C.c_double) for n in (
+        "max_vel_x", "min_vel_x", "max_vel_th", "min_vel_th", "max_trans_acc", "max_rot_acc",
+        "min_in_place_vel_th", "yaw_goal_tolerance", "xy_goal_tolerance", "wp_tolerance", "sim_time",
+        "sim_granularity", "robot_radius", "social_weight", "costmap_weight", "angle_weight",
+        "distance_weight", "vel_weight")] + [("is_circular", C.c_int32), ("precision", C.c_int32)]
+
+
+def default_ctrl_params(**overrides):
+    """ControllerParams() defaults, reference sfw_planner.hpp:56-66."""
+    c = CtrlParams()
+    c.max_vel_x, c.min_vel_x = 0.7, 0.1
+    c.max_vel_th, c.min_vel_th = 0.5, 0.1
+    c.max_trans_acc, c.max_rot_acc = 1.0, 1.0
+    c.min_in_place_vel_th = 0.3
+    c.yaw_goal_tolerance, c.xy_goal_tolerance, c.wp_tolerance = 0.05, 0.1, 0.5
+    c.sim_time, c.sim_granularity = 1.0, 0.025
+    c.robot_radius = float(C.c_float(0.35).value)
+    c.social_weight, c.costmap_weight, c.angle_weight, c.distance_weight, c.vel_weight = 1.2, 2.0, 0.7, 1.0, 1.0
+    c.is_circular, c.precision = 1, SFW_PRECISION_F64
+    for k, v in overrides.items():
+        if not hasattr(c, k):
+            raise AttributeError(f"ControllerParams has no field {k!r}")
+        setattr(c, k, v)
+    return c
+
+
+# SFWPlanner::Branch in host/sfw_planner.hpp (which exit of findBestAction ran)
+BRANCH_NOT_RUNNING, BRANCH_GOAL_REACHED, BRANCH_ROTATE_IN_PLACE, BRANCH_ROTATE_BLOCKED = 0, 1, 2, 3
+BRANCH_APPROACH, BRANCH_GRID, BRANCH_GRID_FAILED = 4, 5, 6

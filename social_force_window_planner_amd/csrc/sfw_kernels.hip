@@ -333,7 +333,7 @@ __device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const R2 
 
 template <typename R> struct lds_layout {
   using R2 = typename vec2<R>::type;
-  R2 *pos, *vel, *frc, *goal, *obs;
+  R2 *pos, *vel, *frc, *frj, *goal, *obs;
   R *gr, *dv, *rad;
   double *swp;
   int *id, *hasgoal, *dead;
@@ -346,6 +346,7 @@ template <typename R> struct lds_layout {
     pos = reinterpret_cast<R2 *>(take(sizeof(R2) * GA));
     vel = reinterpret_cast<R2 *>(take(sizeof(R2) * GA));
     frc = reinterpret_cast<R2 *>(take(sizeof(R2) * GA));
+    frj = reinterpret_cast<R2 *>(take(sizeof(R2) * GA));
     goal = reinterpret_cast<R2 *>(take(sizeof(R2) * A));
     obs = reinterpret_cast<R2 *>(take(sizeof(R2) * (O > 0 ? O : 1)));
     swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
@@ -429,6 +430,7 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel(const sfw_launch L, co
       }
     }
     s.frc[sl] = R2{fx, fy};
+    s.frj[sl] = R2{R(0), R(0)};
   }
   __syncthreads();
 
@@ -461,10 +463,14 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel(const sfw_launch L, co
       const R2 pi = s.pos[si], pj = s.pos[sj], vi = s.vel[si], vj = s.vel[sj];
       R fx, fy;
       pair_force<R>(k, pi.x, pi.y, vi.x, vi.y, pj.x, pj.y, vj.x, vj.y, fx, fy);
+      // Two accumulators per agent: what it receives as the pair's `i` and as its
+      // `j`.  Each one then sums its contributions in item order whatever the
+      // sample's position inside the wave, so a sample's result does not depend
+      // on how samples are packed into waves (or sharded over GPUs).
       atomicAdd(&s.frc[si].x, fx);
       atomicAdd(&s.frc[si].y, fy);
-      atomicAdd(&s.frc[sj].x, -fx);
-      atomicAdd(&s.frc[sj].y, -fy);
+      atomicAdd(&s.frj[sj].x, -fx);
+      atomicAdd(&s.frj[sj].y, -fy);
     }
     __syncthreads();
 
@@ -475,7 +481,13 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel(const sfw_launch L, co
       if (s.dead[g]) continue;
       const sfw_robot_step rs = L.rstep[static_cast<int64_t>(step) * L.rstep_stride + first_local + g];
       const R rx = R(rs.x), ry = R(rs.y), rvx = R(rs.vx), rvy = R(rs.vy);
-      const R2 F = s.frc[sl];
+      R2 F = s.frc[sl];
+      {
+        const R2 Fj = s.frj[sl];
+        F.x += Fj.x;
+        F.y += Fj.y;
+        s.frj[sl] = R2{R(0), R(0)};
+      }
       if (i == 0) {
         // Wr (ref :681-682): robot's social + obstacle force norms at the pre-step state
         R wr = m_sqrt<R>(F.x * F.x + F.y * F.y);
@@ -663,7 +675,7 @@ size_t sfw_social_lds_bytes(int A, int O, int precision) {
   const size_t GA = static_cast<size_t>(G) * A;
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
   size_t n = 0;
-  n += 3 * up(2 * r * GA);                 // pos, vel, frc
+  n += 4 * up(2 * r * GA);                 // pos, vel, frc, frj
   n += up(2 * r * A);                      // goal
   n += up(2 * r * (O > 0 ? O : 1));        // obs
   n += up(8 * GA);                         // swp

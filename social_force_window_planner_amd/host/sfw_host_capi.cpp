@@ -1,0 +1,179 @@
+// sfw_host_capi.cpp — flat C shim over the C++ host mirror so that the Python
+// tests (ctypes) can drive SFWPlanner::findBestAction / updatePlan exactly as
+// nav2's controller_server would.  Test plumbing; the product interface is the
+// C++ class in sfw_planner.hpp.
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <string>
+
+#include "sfw_planner.hpp"
+
+using namespace social_force_window_planner;
+
+extern "C" {
+
+// Numeric ControllerParams, field for field (reference sfw_planner.hpp:186-226).
+typedef struct sfwh_params {
+  double max_vel_x, min_vel_x, max_vel_th, min_vel_th, max_trans_acc, max_rot_acc, min_in_place_vel_th;
+  double yaw_goal_tolerance, xy_goal_tolerance, wp_tolerance;
+  double sim_time, sim_granularity;
+  double robot_radius;  // stored as float, like the reference
+  double social_weight, costmap_weight, angle_weight, distance_weight, vel_weight;
+  int32_t is_circular, precision;
+} sfwh_params;
+
+}  // extern "C"
+
+namespace {
+
+class StaticAgents : public AgentSource {
+ public:
+  AgentSet set;
+  AgentSet getAgents() override { return set; }
+};
+
+struct HostHandle {
+  std::shared_ptr<StaticAgents> agents = std::make_shared<StaticAgents>();
+  std::vector<uint8_t> cells;
+  CostmapView view;
+  std::unique_ptr<SFWPlanner> planner;
+  std::string err;
+};
+
+ControllerParams from_c(const sfwh_params &c) {
+  ControllerParams p;
+  p.max_vel_x_ = c.max_vel_x; p.min_vel_x_ = c.min_vel_x;
+  p.max_vel_th_ = c.max_vel_th; p.min_vel_th_ = c.min_vel_th;
+  p.max_trans_acc_ = c.max_trans_acc; p.max_rot_acc_ = c.max_rot_acc;
+  p.min_in_place_vel_th_ = c.min_in_place_vel_th;
+  p.yaw_goal_tolerance_ = c.yaw_goal_tolerance; p.xy_goal_tolerance_ = c.xy_goal_tolerance;
+  p.wp_tolerance_ = c.wp_tolerance;
+  p.sim_time_ = c.sim_time; p.sim_granularity_ = c.sim_granularity;
+  p.robot_radius_ = static_cast<float>(c.robot_radius);
+  p.social_weight_ = c.social_weight; p.costmap_weight_ = c.costmap_weight;
+  p.angle_weight_ = c.angle_weight; p.distance_weight_ = c.distance_weight; p.vel_weight_ = c.vel_weight;
+  p.is_circular_ = c.is_circular != 0;
+  p.precision_ = c.precision;
+  return p;
+}
+
+template <class F> int guarded(HostHandle *h, F &&f) {
+  try {
+    return f();
+  } catch (const std::exception &e) {
+    h->err = e.what();
+    return -100;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void sfwh_params_default(sfwh_params *c) {
+  ControllerParams p;
+  c->max_vel_x = p.max_vel_x_; c->min_vel_x = p.min_vel_x_;
+  c->max_vel_th = p.max_vel_th_; c->min_vel_th = p.min_vel_th_;
+  c->max_trans_acc = p.max_trans_acc_; c->max_rot_acc = p.max_rot_acc_;
+  c->min_in_place_vel_th = p.min_in_place_vel_th_;
+  c->yaw_goal_tolerance = p.yaw_goal_tolerance_; c->xy_goal_tolerance = p.xy_goal_tolerance_;
+  c->wp_tolerance = p.wp_tolerance_;
+  c->sim_time = p.sim_time_; c->sim_granularity = p.sim_granularity_;
+  c->robot_radius = p.robot_radius_;
+  c->social_weight = p.social_weight_; c->costmap_weight = p.costmap_weight_;
+  c->angle_weight = p.angle_weight_; c->distance_weight = p.distance_weight_; c->vel_weight = p.vel_weight_;
+  c->is_circular = p.is_circular_ ? 1 : 0;
+  c->precision = p.precision_;
+}
+
+void *sfwh_create(const sfwh_params *c, const uint8_t *cells, uint32_t sx, uint32_t sy, double ox, double oy,
+                  double res, const double *footprint_xy, int32_t K, int32_t device) {
+  HostHandle *h = new HostHandle();
+  h->cells.assign(cells, cells + static_cast<size_t>(sx) * sy);
+  h->view = CostmapView{h->cells.data(), sx, sy, ox, oy, res};
+  std::vector<Point> fp;
+  for (int i = 0; i < K; ++i) fp.push_back(Point{footprint_xy[2 * i], footprint_xy[2 * i + 1], 0.0});
+  h->planner.reset(new SFWPlanner(from_c(*c), h->agents, h->view, fp, device));
+  return h;
+}
+void sfwh_destroy(void *hv) { delete static_cast<HostHandle *>(hv); }
+const char *sfwh_last_error(void *hv) { return static_cast<HostHandle *>(hv)->err.c_str(); }
+
+int sfwh_set_params(void *hv, const sfwh_params *c) {
+  HostHandle *h = static_cast<HostHandle *>(hv);
+  return guarded(h, [&] { h->planner->setParams(from_c(*c)); return 0; });
+}
+int sfwh_set_costmap(void *hv, const uint8_t *cells, uint32_t sx, uint32_t sy, double ox, double oy, double res) {
+  HostHandle *h = static_cast<HostHandle *>(hv);
+  h->cells.assign(cells, cells + static_cast<size_t>(sx) * sy);
+  h->view = CostmapView{h->cells.data(), sx, sy, ox, oy, res};
+  h->planner->setCostmap(h->view);
+  return 0;
+}
+int sfwh_set_agents(void *hv, const sfw_agent *agents, int32_t A, const double *obs_xy, int32_t O) {
+  HostHandle *h = static_cast<HostHandle *>(hv);
+  h->agents->set.agents.assign(agents, agents + A);
+  h->agents->set.obstacles_xy.assign(obs_xy, obs_xy + 2 * static_cast<size_t>(O));
+  return 0;
+}
+int sfwh_set_sample_sets(void *hv, const double *lin, int32_t nv, const double *ang, int32_t nw) {
+  HostHandle *h = static_cast<HostHandle *>(hv);
+  h->planner->setSampleSets(std::vector<double>(lin, lin + nv), std::vector<double>(ang, ang + nw));
+  return 0;
+}
+// plan: n poses as (x, y, yaw) triples
+int sfwh_update_plan(void *hv, const double *xyyaw, int32_t n) {
+  HostHandle *h = static_cast<HostHandle *>(hv);
+  std::vector<PoseStamped> plan(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) {
+    plan[i].pose.position.x = xyyaw[3 * i];
+    plan[i].pose.position.y = xyyaw[3 * i + 1];
+    plan[i].pose.orientation = quaternionFromYaw(xyyaw[3 * i + 2]);
+  }
+  return guarded(h, [&] { return h->planner->updatePlan(plan) ? 0 : 1; });
+}
+// pose = (x, y, yaw), vel = (vx, vy, vtheta); cmd_out = (vx, vy, vtheta).
+// *found_out = return value of findBestAction; *branch_out = SFWPlanner::Branch.
+int sfwh_find_best_action(void *hv, const double *pose, const double *vel, double *cmd_out,
+                          int32_t *found_out, int32_t *branch_out) {
+  HostHandle *h = static_cast<HostHandle *>(hv);
+  return guarded(h, [&] {
+    PoseStamped ps;
+    ps.pose.position.x = pose[0];
+    ps.pose.position.y = pose[1];
+    ps.pose.orientation = quaternionFromYaw(pose[2]);
+    Twist tw, cmd;
+    tw.linear.x = vel[0];
+    tw.linear.y = vel[1];
+    tw.angular.z = vel[2];
+    const bool ok = h->planner->findBestAction(ps, tw, cmd);
+    cmd_out[0] = cmd.linear.x;
+    cmd_out[1] = cmd.linear.y;
+    cmd_out[2] = cmd.angular.z;
+    *found_out = ok ? 1 : 0;
+    *branch_out = h->planner->lastBranch();
+    return 0;
+  });
+}
+int sfwh_is_goal_reached(void *hv) { return static_cast<HostHandle *>(hv)->planner->isGoalReached() ? 1 : 0; }
+int sfwh_wp_index(void *hv) { return static_cast<HostHandle *>(hv)->planner->wpIndex(); }
+int sfwh_running(void *hv) { return static_cast<HostHandle *>(hv)->planner->running() ? 1 : 0; }
+int64_t sfwh_last_costs(void *hv, double *out, int64_t cap) {
+  const std::vector<double> &c = static_cast<HostHandle *>(hv)->planner->lastCosts();
+  const int64_t n = static_cast<int64_t>(c.size());
+  if (out) std::memcpy(out, c.data(), sizeof(double) * static_cast<size_t>(n < cap ? n : cap));
+  return n;
+}
+int sfwh_trajectory_points(void *hv, int64_t index, double *xyth, int32_t cap) {
+  HostHandle *h = static_cast<HostHandle *>(hv);
+  return guarded(h, [&] {
+    Trajectory t;
+    if (!h->planner->getTrajectoryPoints(index, t)) return -1;
+    const int n = static_cast<int>(t.getPointsSize());
+    for (int i = 0; i < n && i < cap; ++i) t.getPoint(i, xyth[3 * i], xyth[3 * i + 1], xyth[3 * i + 2]);
+    return n;
+  });
+}
+double sfwh_get_yaw(double x, double y, double z, double w) { return getYaw(Quaternion{x, y, z, w}); }
+}

@@ -99,7 +99,7 @@ def _f64(a):
 
 class HipScorer:
     """The (v,w) grid scorer on one MI355X.  Method-for-method the same surface
-    as oracle.sfw_oracle.OracleScorer."""
+    as the CPU checker's scorer class under oracle/ (which this package never imports)."""
 
     def __init__(self, params: SfwParams | None = None, device: int = 0):
         self.params = params if params is not None else default_params()

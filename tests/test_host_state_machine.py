@@ -1,0 +1,187 @@
+"""C++ host mirror (host/sfw_planner.cpp) vs the oracle's restatement of the
+findBestAction state machine (reference src/sfw_planner.cpp:117-334, :426-468,
+:853-902).  The branches that never score run on CPU; the scoring branches need
+the GPU and must raise without one."""
+import dataclasses
+import math
+
+import numpy as np
+import pytest
+
+from social_force_window_planner_amd import host, synthetic as syn
+from social_force_window_planner_amd._abi import (BRANCH_APPROACH, BRANCH_GOAL_REACHED, BRANCH_GRID,
+                                                   BRANCH_GRID_FAILED, BRANCH_NOT_RUNNING, BRANCH_ROTATE_BLOCKED,
+                                                   BRANCH_ROTATE_IN_PLACE, default_ctrl_params)
+
+
+@pytest.fixture(scope="module")
+def host_built():
+    host.build()
+    return host
+
+
+def _gpu():
+    import torch
+
+    return torch.cuda.is_available()
+
+
+def _pair(oracle_mod, host_built, scene, **ckw):
+    return (oracle_mod.OraclePlanner(default_ctrl_params(**ckw), scene),
+            host_built.HostPlanner(default_ctrl_params(**ckw), scene))
+
+
+def _same(a, b):
+    (fa, ca, ba), (fb, cb, bb) = a, b
+    assert fa == fb and ba == bb
+    assert np.array_equal(ca, cb)
+
+
+def test_not_running_goal_reached_rotate(oracle_mod, host_built):
+    scene = syn.make_scene("ref5x9")
+    o, h = _pair(oracle_mod, host_built, scene)
+    for pl in (o, h):
+        found, cmd, br = pl.find_best_action([0, 0, 0], [0.3, 0, 0])  # no plan yet: ref :131-142
+        assert found and br == BRANCH_NOT_RUNNING and not cmd.any()
+        pl.update_plan(np.zeros((0, 3)))                               # empty plan: ref :866-871
+        assert not pl.running and pl.wp_index == -1
+        pl.update_plan([[0, 0, 0], [0.05, 0.0, 0.5]])
+        assert pl.running and pl.wp_index == 0
+        found, cmd, br = pl.find_best_action([0, 0, 0], [0.3, 0, 0])  # inside xy tolerance, yaw off: rotate
+        assert found and br == BRANCH_ROTATE_IN_PLACE and cmd.tolist() == [0.0, 0.0, 0.3]
+        assert not pl.is_goal_reached() and pl.running
+        found, cmd, br = pl.find_best_action([0, 0, 1.0], [0, 0, 0])  # overshoot: rotate the other way
+        assert cmd.tolist() == [0.0, 0.0, -0.3]
+        found, cmd, br = pl.find_best_action([0.04, 0, 0.48], [0.3, 0, 0])  # within yaw tolerance
+        assert found and br == BRANCH_GOAL_REACHED and not cmd.any() and not pl.running
+        assert pl.is_goal_reached() and not pl.is_goal_reached()        # one-shot flag, ref :894-900
+        found, cmd, br = pl.find_best_action([0.04, 0, 0.48], [0.3, 0, 0])
+        assert br == BRANCH_NOT_RUNNING
+
+
+def test_rotation_uses_float_normalize_angle(oracle_mod, host_built):
+    """goal yaw 3.0, robot yaw -3.0: the float-normalised difference is negative."""
+    scene = syn.make_scene("ref5x9")
+    o, h = _pair(oracle_mod, host_built, scene)
+    for pl in (o, h):
+        pl.update_plan([[0, 0, 3.0]])
+        _, cmd, br = pl.find_best_action([0, 0, -3.0], [0, 0, 0])
+        assert br == BRANCH_ROTATE_IN_PLACE and cmd[2] == -0.3
+
+
+def test_get_yaw(host_built):
+    L = host_built.lib()
+    for yaw in (-3.1, -1.0, 0.0, 0.5, 2.0, 3.1):
+        assert L.sfwh_get_yaw(0.0, 0.0, math.sin(yaw / 2), math.cos(yaw / 2)) == pytest.approx(yaw, abs=1e-15)
+
+
+@pytest.mark.skipif(_gpu(), reason="a GPU is visible")
+def test_scoring_branches_raise_without_gpu(host_built):
+    scene = syn.make_scene("ref5x9")
+    h = host_built.HostPlanner(default_ctrl_params(), scene)
+    h.update_plan([[x, 0.0, 0.0] for x in np.linspace(0, 4, 9)])
+    with pytest.raises(RuntimeError, match="no CPU scoring path"):
+        h.find_best_action([0, 0, 0], [0.3, 0, 0])
+
+
+# ---------------------------------------------------------------------------
+# GPU: full cycles incl. the grid, the approach branch and the non-circular rotation
+# ---------------------------------------------------------------------------
+def _plan():
+    return [[x, 0.15 * x, 0.2] for x in np.linspace(0.0, 4.0, 17)]
+
+
+@pytest.mark.gpu
+def test_grid_branch_matches_oracle_over_a_drive(oracle_mod, host_built):
+    scene = syn.make_scene("ref5x9")
+    o, h = _pair(oracle_mod, host_built, scene)
+    for pl in (o, h):
+        pl.update_plan(_plan())
+    pose, vel = np.array([0.0, 0.0, 0.0]), np.array([0.3, 0.0, 0.0])
+    for cycle in range(6):
+        used_pose = pose.copy()
+        ro = o.find_best_action(pose, vel)
+        rh = h.find_best_action(pose, vel)
+        assert ro[2] == BRANCH_GRID
+        _same(ro, rh)
+        assert o.wp_index == h.wp_index
+        co, ch = o.last_costs(), h.last_costs()
+        assert np.array_equal(co < 0, ch < 0)
+        v = co >= 0
+        assert np.max(np.abs(co[v] - ch[v]) / np.abs(co[v])) <= 1e-9
+        # drive the robot with the command for 0.3 s (way-points advance, ref :258-271)
+        cmd = ro[1]
+        pose = pose + np.array([cmd[0] * math.cos(pose[2]) * 0.3, cmd[0] * math.sin(pose[2]) * 0.3, cmd[2] * 0.3])
+        vel = np.array([cmd[0], 0.0, cmd[2]])
+    assert o.wp_index > 1
+    pts = h.trajectory_points(int(np.flatnonzero(h.last_costs() >= 0)[0]))
+    assert pts.shape == (40, 3) and np.allclose(pts[0], np.float32(used_pose), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_new_plan_picks_closest_waypoint_from_the_end(oracle_mod, host_built):
+    scene = syn.make_scene("ref5x9")
+    o, h = _pair(oracle_mod, host_built, scene)
+    loop = [[0, 0, 0], [1, 0, 0], [2, 0, 0], [2, 1, 0], [1, 1, 0], [0.2, 0.3, 0], [3, 3, 0]]
+    for pl in (o, h):
+        pl.update_plan(loop)
+        pl.find_best_action([0.0, 0.0, 0.0], [0.3, 0, 0])
+    assert o.wp_index == h.wp_index == 6  # index 5 is within wp_tolerance (searched from the end), then advanced
+
+
+@pytest.mark.gpu
+def test_approach_branch(oracle_mod, host_built):
+    scene = syn.make_scene("ref5x9")
+    o, h = _pair(oracle_mod, host_built, scene)
+    for pl in (o, h):
+        pl.update_plan([[0, 0, 0], [0.5, 0.2, 0.0], [1.0, 0.4, 0.0]])  # goal 1.08 m away: < dist_thres 1.5
+    ro, rh = o.find_best_action([0, 0, 0], [0.3, 0, 0]), h.find_best_action([0, 0, 0], [0.3, 0, 0])
+    assert ro[2] == BRANCH_APPROACH
+    _same(ro, rh)
+    assert ro[1][0] == pytest.approx(0.1 + 0.6 * math.hypot(1.0, 0.4) / 1.5, rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_approach_blocked_falls_through_to_grid_and_grid_can_fail(oracle_mod, host_built):
+    """A lethal wall right in front of the robot: the approach command is
+    rejected (ref :327-333), the grid runs, and when every sample is rejected
+    findBestAction returns false with a zero command (ref :456-468)."""
+    scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["ref5x9"], n_people=0))
+    cells = scene.cells.copy()
+    cells[:, 104:108] = 254  # wall at x = 0.2..0.4 m
+    scene.cells[:] = cells
+    o, h = _pair(oracle_mod, host_built, scene)
+    for pl in (o, h):
+        pl.update_plan([[0, 0, 0], [0.5, 0.0, 0.0], [1.0, 0.0, 0.0]])
+    ro, rh = o.find_best_action([0, 0, 0], [0.3, 0, 0]), h.find_best_action([0, 0, 0], [0.3, 0, 0])
+    _same(ro, rh)
+    assert ro[2] in (BRANCH_GRID, BRANCH_GRID_FAILED)
+    # box the robot in completely: every sample's first pose is already illegal
+    cells[:] = 254
+    for pl in (o, h):
+        pl.set_costmap(cells, scene.origin_x, scene.origin_y, scene.resolution)
+    ro, rh = o.find_best_action([0, 0, 0], [0.3, 0, 0]), h.find_best_action([0, 0, 0], [0.3, 0, 0])
+    _same(ro, rh)
+    assert ro[0] is False and ro[2] == BRANCH_GRID_FAILED and not ro[1].any()
+
+
+@pytest.mark.gpu
+def test_non_circular_rotation_check(oracle_mod, host_built):
+    """ref :202-220: with is_circular=false the in-place rotation is scored; a
+    long box footprint next to a wall cannot rotate."""
+    w = dataclasses.replace(syn.WORKLOADS["ref5x9"], n_people=0, footprint="box")
+    scene = syn.make_scene(w)
+    o, h = _pair(oracle_mod, host_built, scene, is_circular=0)
+    for pl in (o, h):
+        pl.update_plan([[0, 0, 1.0]])
+    ro, rh = o.find_best_action([0, 0, 0], [0, 0, 0]), h.find_best_action([0, 0, 0], [0, 0, 0])
+    _same(ro, rh)
+    assert ro[0] and ro[2] == BRANCH_ROTATE_IN_PLACE
+    cells = scene.cells.copy()
+    cells[107:109, :] = 254  # wall at y = 0.35..0.45: the 0.4 m half-length box hits it while turning
+    for pl in (o, h):
+        pl.set_costmap(cells, scene.origin_x, scene.origin_y, scene.resolution)
+        pl.update_plan([[0, 0, 1.0]])
+    ro, rh = o.find_best_action([0, 0, 0], [0, 0, 0]), h.find_best_action([0, 0, 0], [0, 0, 0])
+    _same(ro, rh)
+    assert ro[0] is False and ro[2] == BRANCH_ROTATE_BLOCKED and ro[1].tolist() == [0.0, 0.0, 0.3]

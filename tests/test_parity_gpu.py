@@ -6,6 +6,7 @@ sides differ only in libm last-ulp and summation order); the identical-invalid-s
 and identical-argmin checks are exact.
 """
 import dataclasses
+import math
 
 import numpy as np
 import pytest
@@ -62,3 +63,267 @@ def test_people_counts(oracle_mod, hip_mod, n_people):
     w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=8, nw=9, n_people=n_people, seed=100 + n_people)
     _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w)
     _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+@pytest.mark.parametrize("fp", ["point", "polygon16", "box"])
+@pytest.mark.parametrize("n_obs", [0, 1, 64])
+def test_footprints_and_laser_points(oracle_mod, hip_mod, fp, n_obs):
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=7, nw=8, n_people=12, footprint=fp, n_obstacles=n_obs,
+                            seed=200 + n_obs)
+    _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+def test_laser_points_without_people(oracle_mod, hip_mod):
+    """A = 1 (robot only) with O > 0: social work = the robot's obstacle-force norm (ref :681-682)."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=9, nw=9, n_people=0, n_obstacles=16, seed=5)
+    _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+@pytest.mark.parametrize("sim_time,gran", [(1.5, 0.25), (2.0, 0.025), (0.01, 0.025), (0.3, 0.1)])
+def test_step_counts(oracle_mod, hip_mod, sim_time, gran):
+    """S = 6 (shipped yaml), 80, 1 (degenerate), 3."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=6, nw=6, n_people=9, sim_time=sim_time, sim_granularity=gran,
+                            seed=9)
+    _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+def _custom(oracle_mod, hip_mod, scene, params=None, lin=None, ang=None, rs=None, ga=None):
+    p = params or default_params()
+    o = oracle_mod.OracleScorer(p)
+    o.load_scene(scene)
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    lin = scene.linvels if lin is None else lin
+    ang = scene.angvels if ang is None else ang
+    rs = scene.robot_state if rs is None else rs
+    ga = scene.goal_args if ga is None else ga
+    oc, ob = o.score_grid(rs, lin, ang, ga, n_threads=8)
+    gc, gb = g.score_grid(rs, lin, ang, ga)
+    return oc, ob, gc, gb, o, g
+
+
+def test_rejections_costmap_collision_offmap(oracle_mod, hip_mod):
+    """The three rejection causes (ref :545-573 costmap/off-map, :613-627 dynamic
+    collision) all occur and the invalid sets are identical."""
+    import golden_util as gu
+
+    fx = gu.Fixture("blocked")
+    p = fx.params()
+    o = oracle_mod.OracleScorer(p)
+    fx.load_into(o)
+    g = hip_mod.HipScorer(p)
+    fx.load_into(g)
+    lin, ang = syn.generalised_sampler(24, 25, 0.7, 1.2)
+    oc, ob = o.score_grid(fx.robot_state, lin, ang, fx.goal_args, n_threads=8)
+    gc, gb = g.score_grid(fx.robot_state, lin, ang, fx.goal_args)
+    assert 50 < (oc == -1).sum() < len(oc) - 50
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+    # robot next to the map edge: trajectories leave the map (-3) or touch the 255 border (-2)
+    rs = (2.3, 0.0, 0.0, float(np.float32(0.3)), 0.0, 0.0)
+    oc, ob = o.score_grid(rs, lin, ang, fx.goal_args, n_threads=8)
+    gc, gb = g.score_grid(rs, lin, ang, fx.goal_args)
+    assert (oc == -1).any() and (oc >= 0).any()
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+def test_all_samples_invalid(oracle_mod, hip_mod):
+    """Every trajectory rejected: best index -1, zero command, status OK (ref :456-468)."""
+    scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["ref5x9"], n_people=3))
+    scene.cells[:] = 254
+    oc, ob, gc, gb, _, _ = _custom(oracle_mod, hip_mod, scene)
+    assert (oc[1:] == -1).all() and oc[0] == -2
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+    assert gb["index"] == -1 and gb["cost"] == -1.0 and gb["vx"] == 0.0 and gb["vtheta"] == 0.0 and gb["n_valid"] == 0
+
+
+def test_people_without_goals_and_goal_pop_and_speed_clamp(oracle_mod, hip_mod):
+    """has_goal=0 people brake (-v/tau); people starting 1 step from their goal pop
+    it mid-rollout; people faster than desiredVelocity are clamped (lightsfm
+    computeDesiredForce/updatePosition)."""
+    scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["cfg2"], nv=6, nw=7, n_people=12, seed=77))
+    ag = scene.agents
+    for i in (1, 2, 3):
+        ag[i].has_goal = 0
+    for i in (4, 5, 6):  # goal 0.4 m ahead with radius 0.35: reached after a few steps
+        sp = math.hypot(ag[i].vx, ag[i].vy)
+        ag[i].goal_x, ag[i].goal_y = ag[i].x + 0.4 * ag[i].vx / sp, ag[i].y + 0.4 * ag[i].vy / sp
+    for i in (7, 8):     # running people: 2.5 m/s > desiredVelocity 1.0
+        sp = math.hypot(ag[i].vx, ag[i].vy)
+        ag[i].vx, ag[i].vy = 2.5 * ag[i].vx / sp, 2.5 * ag[i].vy / sp
+    ag[9].desired_velocity, ag[9].radius, ag[9].goal_radius = 1.7, 0.25, 0.1
+    oc, ob, gc, gb, _, _ = _custom(oracle_mod, hip_mod, scene)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+def test_robot_id_collides_with_a_person_id(oracle_mod, hip_mod):
+    """Wp skips the person whose id equals the robot's (lightsfm skips by id, ref :697)."""
+    scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["cfg2"], nv=5, nw=6, n_people=6, seed=31))
+    oc0, _, _, _, _, _ = _custom(oracle_mod, hip_mod, scene)
+    scene.agents[0].id = 3
+    oc, ob, gc, gb, _, _ = _custom(oracle_mod, hip_mod, scene)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+    assert not np.array_equal(oc, oc0)
+
+
+def test_nondefault_weights_params_and_robot_state(oracle_mod, hip_mod):
+    """config/local_planner.yaml-like values, a moving, rotated robot off the map centre."""
+    scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["cfg2"], nv=8, nw=9, n_people=15, seed=88,
+                                               sim_time=1.5, sim_granularity=0.25))
+    p = default_params(sim_time=1.5, sim_granularity=0.25, max_vel_x=0.8, robot_radius=0.4, social_weight=2.0,
+                       costmap_weight=2.0, vel_weight=0.8, angle_weight=0.6, distance_weight=1.0)
+    rs = tuple(float(np.float32(v)) for v in (0.37, -0.21, 0.9, 0.55, 0.0, -0.4))
+    ga = (0.15, 0.0, 0.52, -1.0, 2.0)
+    lin, ang = syn.generalised_sampler(8, 9, 0.8, 1.57)
+    oc, ob, gc, gb, _, _ = _custom(oracle_mod, hip_mod, scene, params=p, lin=lin, ang=ang, rs=rs, ga=ga)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+def test_score_one_points_and_holonomic(oracle_mod, hip_mod):
+    """scoreTrajectory single-sample call sites (ref :204-206, :299-301) incl. the
+    Trajectory points (ref :578) and a vy_samp != 0 command (ref :582, :586-587)."""
+    scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["cfg2"], n_people=8, seed=12))
+    p = default_params()
+    o = oracle_mod.OracleScorer(p)
+    o.load_scene(scene)
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    ga = (1.0, 0.7, 1.0, 2.0, 0.5)
+    for (vx, vy, vth) in [(0.5, 0.0, 0.2), (0.0, 0.0, 0.3), (0.0, 0.0, 0.0), (0.4, 0.25, -0.3), (0.7, -0.1, 0.0)]:
+        co, po = o.score_one(scene.robot_state, vx, vy, vth, ga)
+        cg, pg = g.score_one(scene.robot_state, vx, vy, vth, ga)
+        assert (co < 0) == (cg < 0)
+        if co >= 0:
+            assert cg == pytest.approx(co, rel=RTOL_F64)
+        assert po.shape == pg.shape and np.allclose(po, pg, rtol=0, atol=1e-13)
+    # an invalid one: the points stop at the first illegal pose
+    scene.cells[:, 110:114] = 254
+    o.load_scene(scene)
+    g.load_scene(scene)
+    co, po = o.score_one(scene.robot_state, 0.7, 0.0, 0.0, ga)
+    cg, pg = g.score_one(scene.robot_state, 0.7, 0.0, 0.0, ga)
+    assert co == cg == -1.0 and 0 < len(po) < 40 and po.shape == pg.shape and np.allclose(po, pg, atol=1e-13)
+
+
+def test_chunked_launch_equals_unchunked(oracle_mod, hip_mod, monkeypatch):
+    """The K1->K2 robot-step table is processed in chunks when it would exceed
+    the budget; results must not depend on the chunking."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=40, nw=41, n_people=7, seed=3)
+    scene = syn.make_scene(w)
+    p = default_params()
+    g1 = hip_mod.HipScorer(p)
+    g1.load_scene(scene)
+    c1, b1 = g1.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    monkeypatch.setenv("SFW_TABLE_BUDGET_MB", "1")  # 1 MiB -> chunk floor of 1024 samples < 1640
+    g2 = hip_mod.HipScorer(p)
+    g2.load_scene(scene)
+    c2, b2 = g2.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert np.array_equal(c1, c2) and b1 == b2
+
+
+def test_cfg2_full_grid(oracle_mod, hip_mod):
+    """BASELINE.json configs[1] at full size against the (multi-threaded) oracle."""
+    _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, syn.WORKLOADS["cfg2"], n_threads=64)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+def test_target_subgrid(oracle_mod, hip_mod):
+    """North-star target shape (50 pedestrians, 40 steps), 32x32 samples."""
+    w = dataclasses.replace(syn.WORKLOADS["target"], nv=32, nw=32)
+    _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w, n_threads=64)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+def test_dense_crowd_subgrid(oracle_mod, hip_mod):
+    """cfg4 shape (200 pedestrians: > 64 agents, several agent slots per lane), 6x6 samples."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg4"], nv=6, nw=6)
+    _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w, n_threads=36)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+# ---------------------------------------------------------------------------
+# Full BASELINE sizes: size-independent properties instead of the oracle
+# ---------------------------------------------------------------------------
+def _full_size_properties(hip_mod, w, subrows):
+    scene = syn.make_scene(w)
+    p = _params_for(w)
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    costs, best = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    nw = len(scene.angvels)
+    grid = costs.reshape(len(scene.linvels), nw)
+    # (1) determinism: a second launch is bit-identical
+    costs2, best2 = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert np.array_equal(costs, costs2) and best == best2
+    # (2) sample independence: scoring a subset of rows alone (different wave packing,
+    #     different grid size) reproduces exactly those rows
+    rows = np.asarray(subrows)
+    sub, _ = g.score_grid(scene.robot_state, scene.linvels[rows], scene.angvels, scene.goal_args)
+    assert np.array_equal(sub.reshape(len(rows), nw), grid[rows])
+    # (3) the device argmin equals the reference's sequential selection over the cost vector
+    sel = _numpy_selection(scene.linvels, scene.angvels, costs)
+    assert best["index"] == sel and best["n_valid"] == int((costs >= 0).sum())
+    if sel >= 0:
+        assert best["cost"] == costs[sel] and best["vx"] == scene.linvels[sel // nw]
+    # (4) costs are finite, >= 0 or one of the two sentinels
+    assert np.all(np.isfinite(costs)) and np.all((costs >= 0) | (costs == -1.0) | (costs == -2.0))
+    return scene, costs, best
+
+
+def _numpy_selection(lin, ang, costs):
+    nw = len(ang)
+    c = costs.reshape(len(lin), nw)
+    L = np.broadcast_to(lin[:, None], c.shape)
+    A = np.broadcast_to(np.abs(ang)[None, :], c.shape)
+    ok = (c >= 0) & ((c < 1e4) | ((c == 1e4) & ((L > 0) | ((L == 0) & (A == 0)))))
+    if not ok.any():
+        return -1
+    idx = np.arange(c.size).reshape(c.shape)
+    order = np.lexsort((-idx[ok], A[ok], -L[ok], c[ok]))  # last key is primary
+    return int(idx[ok][order[0]])
+
+
+def test_cfg3_full_size_properties(oracle_mod, hip_mod):
+    """256x256 grid, 50 pedestrians, 500x500 map, 80 steps."""
+    scene, costs, best = _full_size_properties(hip_mod, syn.WORKLOADS["cfg3"], [0, 17, 128, 255])
+    # spot-check 3 rows against the oracle
+    o = oracle_mod.OracleScorer(_params_for(scene.workload))
+    o.load_scene(scene)
+    rows = [3, 200, 255]
+    oc, _ = o.score_grid(scene.robot_state, scene.linvels[rows], scene.angvels, scene.goal_args, n_threads=64)
+    gc = costs.reshape(256, 256)[rows].ravel()
+    assert np.array_equal(oc < 0, gc < 0)
+    v = oc >= 0
+    assert np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64
+
+
+def test_cfg4_full_size_properties(hip_mod):
+    """1024x1024 grid, 200 pedestrians (dense crowd): the LDS people-tiling stress config."""
+    _full_size_properties(hip_mod, syn.WORKLOADS["cfg4"], [0, 511, 1023])
+
+
+def test_multi_gpu_key_and_index_base(hip_mod):
+    """Row shards scored with index_base reproduce the single-launch selection
+    through the 4-double exchange key (what each rank contributes to the all-reduce)."""
+    from social_force_window_planner_amd import multi_gpu
+
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=24, nw=16, n_people=6, seed=17)
+    scene = syn.make_scene(w)
+    g = hip_mod.HipScorer(_params_for(w))
+    g.load_scene(scene)
+    full, best = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    keys, parts = [], []
+    for r in range(3):
+        lo, hi = multi_gpu.shard_rows(w.nv, r, 3)
+        g.stage(scene.robot_state, scene.linvels[lo:hi], scene.angvels, scene.goal_args, index_base=lo * w.nw)
+        g.launch()
+        c, b, k = g.fetch()
+        parts.append(c)
+        keys.append(k)
+        assert k == multi_gpu.key_from_best(b, scene.linvels[lo:hi], scene.angvels, w.nw, lo * w.nw)
+    assert np.array_equal(np.concatenate(parts), full)
+    _, win = multi_gpu.lexicographic_min(keys)
+    vx, vth, idx = multi_gpu.cmd_from_key(win, w.nw, scene.linvels, scene.angvels)
+    assert (idx, vx, vth) == (best["index"], best["vx"], best["vtheta"])
