@@ -113,9 +113,10 @@ class GridJob:
         prec = SFW_PRECISION_F32 if precision == "f32" else SFW_PRECISION_F64
         self.scorer = HipScorer(default_params(precision=prec, **self.params_kw), device=device)
         self.scorer.load_scene(self.scene)
-        rows = w.nv // world
-        self.row0 = rank * rows
-        self.lin = self.scene.linvels[self.row0:self.row0 + rows]
+        from social_force_window_planner_amd import multi_gpu
+
+        self.row0, row1 = multi_gpu.shard_rows(w.nv, rank, world)
+        self.lin = self.scene.linvels[self.row0:row1]
         self.ang = self.scene.angvels
         self.index_base = self.row0 * len(self.ang)
         self.n_local = len(self.lin) * len(self.ang)
@@ -135,16 +136,15 @@ def run_single_config(workload_name, precision, steps, warmup, dist_ctx):
     rank, world, device = dist_ctx["rank"], dist_ctx["world"], dist_ctx["device"]
     job = GridJob(workload_name, precision, rank, world, device)
     dist = dist_ctx.get("dist")
-    slots = None
-    if dist is not None:
-        slots = torch.empty((world, 4), dtype=torch.float64, device=f"cuda:{device}")
+    from social_force_window_planner_amd import multi_gpu
+
+    state = {"win": (0, None)}
 
     def one_step():
         best, key = job.step()
         if dist is not None:  # single all-reduce(min): every rank fills its own row, +inf elsewhere
-            slots.fill_(float("inf"))
-            slots[rank] = torch.tensor(key, dtype=torch.float64)
-            dist.all_reduce(slots, op=dist.ReduceOp.MIN)
+            wr, wk, _ = multi_gpu.exchange_best(key, dist, rank, world, device=f"cuda:{device}")
+            state["win"] = (wr, wk)
         return best, key
 
     for _ in range(warmup):
@@ -172,8 +172,7 @@ def run_single_config(workload_name, precision, steps, warmup, dist_ctx):
         tot = torch.tensor([float(job.n_scored)], dtype=torch.float64, device=f"cuda:{device}")
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         n_scored_total = int(tot.item())
-        from social_force_window_planner_amd.planner import select_across_ranks
-        win_rank, win_key = select_across_ranks(slots.cpu().numpy())
+        win_rank, win_key = state["win"]
     else:
         n_scored_total = job.n_scored
         win_rank, win_key = 0, key

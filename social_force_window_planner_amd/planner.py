@@ -209,17 +209,3 @@ class HipScorer:
         self._check(lib().sfw_grid_points(self._h, index, pts.ctypes.data, points_cap, C.byref(n)),
                     "sfw_grid_points")
         return pts[: min(n.value, points_cap)].copy()
-
-
-def select_across_ranks(keys):
-    """Lexicographic minimum over per-rank sfw_best_key tuples: the reference's
-    selection order (cost up, linvel down, |angvel| up, iteration index down).
-    Returns (rank, key) or (None, None) when no rank holds a selectable sample."""
-    best_rank, best_key = None, None
-    for r, k in enumerate(keys):
-        k = tuple(float(x) for x in k)
-        if not np.isfinite(k[0]):
-            continue
-        if best_key is None or k < best_key:
-            best_rank, best_key = r, k
-    return best_rank, best_key
