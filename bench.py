@@ -33,6 +33,9 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md
 
 
+GRID_OVERRIDE = None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,6 +45,7 @@ def parse_args():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (target-config) measurement")
+    ap.add_argument("--grid", default=None, help="override the sample grid, e.g. 512x512 (experiments only)")
     ap.add_argument("--verify", action="store_true", help="check the GPU result against the oracle on a sample subset")
     return ap.parse_args()
 
@@ -105,6 +109,9 @@ class GridJob:
         from social_force_window_planner_amd.planner import HipScorer
 
         w = syn.WORKLOADS[workload_name]
+        if GRID_OVERRIDE:
+            nv, nw = (int(v) for v in GRID_OVERRIDE.lower().split("x"))
+            w = dataclasses.replace(w, nv=nv, nw=nw)
         if world > 1:  # weak scaling: N-times more linvel rows, this rank takes its block
             w = dataclasses.replace(w, nv=w.nv * world)
         self.workload = w
@@ -220,6 +227,8 @@ def roofline_for(job, k2_ms, precision):
 
 def main():
     args = parse_args()
+    global GRID_OVERRIDE
+    GRID_OVERRIDE = args.grid
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -24,8 +24,10 @@
 // contraction: vector ALU work, no MFMA.
 
 #include "sfw_device.h"
+#include "sfw_math.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -231,77 +233,88 @@ __global__ void __launch_bounds__(256) sfw_costmap_scan_kernel(const sfw_launch 
 // ===========================================================================
 // K2: social-force integration, one wave per G samples
 // ===========================================================================
+// Agent STATE (position, velocity), its integration and every discrete
+// threshold (contact, goal pop, speed clamp) are always double.  The template
+// type R is the type the FORCES are evaluated in: double (parity mode) or float
+// (fast mode: differences are formed in double, then rounded to float).
 template <typename R> struct vec2;
 template <> struct vec2<double> { using type = double2; };
 template <> struct vec2<float> { using type = float2; };
+template <typename R> struct tiny_of;
+template <> struct tiny_of<double> { static constexpr double v = 1e-300; };
+template <> struct tiny_of<float> { static constexpr float v = 1e-30f; };
 
-template <typename R> __device__ __forceinline__ R m_sqrt(R x);
-template <> __device__ __forceinline__ double m_sqrt<double>(double x) { return sqrt(x); }
-template <> __device__ __forceinline__ float m_sqrt<float>(float x) { return sqrtf(x); }
-template <typename R> __device__ __forceinline__ R m_rsqrt(R x);
-template <> __device__ __forceinline__ double m_rsqrt<double>(double x) { return rsqrt(x); }
-template <> __device__ __forceinline__ float m_rsqrt<float>(float x) { return rsqrtf(x); }
-template <typename R> __device__ __forceinline__ R m_exp(R x);
-template <> __device__ __forceinline__ double m_exp<double>(double x) { return exp(x); }
-template <> __device__ __forceinline__ float m_exp<float>(float x) { return expf(x); }
-template <typename R> __device__ __forceinline__ R m_atan2(R y, R x);
-template <> __device__ __forceinline__ double m_atan2<double>(double y, double x) { return atan2(y, x); }
-template <> __device__ __forceinline__ float m_atan2<float>(float y, float x) { return atan2f(y, x); }
-
-// Per-launch social-force constants in the kernel's real type.
+// Per-launch social-force constants in the force type.
 template <typename R> struct sfm_consts {
+  sfwm::poly_consts pc;
   R lambda, gamma, inv_gamma, n, n_prime, f_social;
-  R f_desired, inv_tau, f_obstacle, inv_sigma;
-  R dt, rr;
+  R f_obstacle, inv_sigma;
+  double f_desired, inv_tau, dt, rr;
 };
 
 // Force exerted ON agent i BY agent j (one term of lightsfm's
-// computeSocialForce).  The term is antisymmetric under
-// i<->j when every agent carries the same sfm::Parameters (the reference never
-// overrides them), so the caller applies -f to j and evaluates each unordered
-// pair once.
-//   diff = pj - pi, dhat = diff/|diff|, w = vi - vj, I = lambda*w + dhat,
-//   theta = angle(dhat) - angle(I) = atan2(I x diff, I . diff)   in (-pi, pi]
+// computeSocialForce), from diff = pj - pi and
+// w = vi - vj.  Antisymmetric under i<->j when every agent carries the same
+// sfm::Parameters (the reference never overrides them), so the caller applies -f
+// to j and evaluates each unordered pair once.
+//   dhat = diff/|diff|, I = lambda*w + dhat,
+//   theta = angle(dhat) - angle(I) = atan2(I x dhat, I . dhat)   in (-pi, pi]
+//   sign(theta) = sign(w x diff)   (I x dhat = lambda * w x dhat exactly)
 //   B = gamma*|I|
 //   f = Fs * ( -exp(-|diff|/B - (n' B theta)^2) * Ihat
 //              - sign(theta) * exp(-|diff|/B - (n B theta)^2) * leftNormal(Ihat) )
+// cw = w x diff evaluated in double by the caller (exact sign in both modes).
 template <typename R>
-__device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R pix, R piy, R vix, R viy, R pjx,
-                                           R pjy, R vjx, R vjy, R &fx, R &fy) {
-  const R dx = pjx - pix, dy = pjy - piy;
-  const R d2 = dx * dx + dy * dy;
-  const R rd = d2 > R(0) ? m_rsqrt<R>(d2) : R(0);  // zero vector stays zero (normalized())
-  const R dn = d2 * rd;
-  const R ix = k.lambda * (vix - vjx) + dx * rd;
-  const R iy = k.lambda * (viy - vjy) + dy * rd;
-  const R l2 = ix * ix + iy * iy;
-  const R rl = m_rsqrt<R>(l2);
-  const R il = l2 * rl;
-  const R ihx = ix * rl, ihy = iy * rl;
-  const R cr = ix * dy - iy * dx;   // |I||diff| sin(theta)
-  const R dt = ix * dx + iy * dy;   // |I||diff| cos(theta)
-  const R theta = m_atan2<R>(cr, dt);
-  const R B = k.gamma * il;
-  const R a = -dn * rl * k.inv_gamma;  // -|diff| / B
-  const R bt = B * theta;
+__device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R wx, R wy, double cw, R &fx,
+                                           R &fy) {
+  using namespace sfwm;
+  const R tiny = tiny_of<R>::v;
+  R rd, dn, rl, il;
+  const R d2 = fmax(fma(dx, dx, dy * dy), tiny);  // coincident agents: dhat -> 0, no NaN
+  rsqrt_sqrt(d2, rd, dn);
+  const R ux = dx * rd, uy = dy * rd;
+  const R ix = fma(k.lambda, wx, ux), iy = fma(k.lambda, wy, uy);
+  const R l2 = fmax(fma(ix, ix, iy * iy), tiny);
+  rsqrt_sqrt(l2, rl, il);
+  const R sn = fma(ix, uy, -(iy * ux));  // |I| sin(theta)
+  const R cs = fma(ix, ux, iy * uy);     // |I| cos(theta)
+  const R theta = atan2_abs(k.pc, fabs(sn), cs);
+  const R a = -dn * rl * k.inv_gamma;    // -|diff| / B
+  const R bt = k.gamma * il * theta;     // B * |theta|
   const R sv = k.n_prime * bt, sa = k.n * bt;
-  const R ev = m_exp<R>(a - sv * sv);
-  R ea = m_exp<R>(a - sa * sa);
-  ea = theta > R(0) ? ea : (theta < R(0) ? -ea : R(0));  // sign(theta) * exp(...)
-  // f = Fs * (-ev * Ihat - ea * leftNormal(Ihat)),  leftNormal(x,y) = (-y, x)
-  fx = k.f_social * (ea * ihy - ev * ihx);
-  fy = -k.f_social * (ev * ihy + ea * ihx);
+  const R ev = exp_fast(k.pc, fma(-sv, sv, a));
+  R ea = exp_fast(k.pc, fma(-sa, sa, a));
+  ea = cw > 0.0 ? ea : (cw < 0.0 ? -ea : R(0));  // sign(theta) * exp(...)
+  const R sc = rl * k.f_social;
+  const R gx = ix * sc, gy = iy * sc;    // Fs * Ihat
+  // f = -ev * (Fs Ihat) - ea * leftNormal(Fs Ihat),  leftNormal(x,y) = (-y, x)
+  fx = fma(ea, gy, -(ev * gx));
+  fy = -fma(ev, gy, ea * gx);
+}
+template <typename R>
+__device__ __forceinline__ void pair_force_state(const sfm_consts<R> &k, double pix, double piy, double vix,
+                                                 double viy, double pjx, double pjy, double vjx, double vjy,
+                                                 R &fx, R &fy) {
+  const double dx = pjx - pix, dy = pjy - piy, wx = vix - vjx, wy = viy - vjy;
+  const double cw = fma(wx, dy, -(wy * dx));
+  pair_force<R>(k, R(dx), R(dy), R(wx), R(wy), cw, fx, fy);
 }
 
-// desiredForce of one person (lightsfm computeDesiredForce).
+__device__ __forceinline__ double fast_norm(double x, double y) {
+  double rs, sq;
+  sfwm::rsqrt_sqrt(fmax(fma(x, x, y * y), 1e-300), rs, sq);
+  return sq;
+}
+
+// desiredForce of one person (lightsfm computeDesiredForce), double.
 template <typename R>
-__device__ __forceinline__ void desired_force(const sfm_consts<R> &k, R px, R py, R vx, R vy, bool has_goal,
-                                              R gx, R gy, R gr, R dv, R &fx, R &fy) {
-  const R ex = gx - px, ey = gy - py;
-  const R e2 = ex * ex + ey * ey;
-  const R en = m_sqrt<R>(e2);
+__device__ __forceinline__ void desired_force(const sfm_consts<R> &k, double px, double py, double vx, double vy,
+                                              bool has_goal, double gx, double gy, double gr, double dv, double &fx,
+                                              double &fy) {
+  const double ex = gx - px, ey = gy - py;
+  double inv, en;
+  sfwm::rsqrt_sqrt(fmax(fma(ex, ex, ey * ey), 1e-300), inv, en);
   if (has_goal && en > gr) {
-    const R inv = en > R(0) ? R(1) / en : R(0);
     fx = k.f_desired * (ex * inv * dv - vx) * k.inv_tau;
     fy = k.f_desired * (ey * inv * dv - vy) * k.inv_tau;
   } else {
@@ -313,29 +326,27 @@ __device__ __forceinline__ void desired_force(const sfm_consts<R> &k, R px, R py
 // obstacleForce of one agent: mean over the shared laser points (lightsfm
 // computeObstacleForce).  obs lives in LDS; every lane reads the same address
 // (broadcast).
-template <typename R, typename R2>
-__device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const R2 *obs, int O, R inv_O, R px,
-                                               R py, R radius, R &fx, R &fy) {
+template <typename R>
+__device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const double2 *obs, int O, double inv_O,
+                                               double px, double py, double radius, double &fx, double &fy) {
+  using namespace sfwm;
   R ax = R(0), ay = R(0);
   for (int o = 0; o < O; ++o) {
-    const R2 q = obs[o];
-    const R mx = px - q.x, my = py - q.y;
-    const R m2 = mx * mx + my * my;
-    const R rm = m2 > R(0) ? m_rsqrt<R>(m2) : R(0);
-    const R dist = m2 * rm - radius;
-    const R e = k.f_obstacle * m_exp<R>(-dist * k.inv_sigma);
-    ax += e * mx * rm;
-    ay += e * my * rm;
+    const double2 q = obs[o];
+    const R mx = R(px - q.x), my = R(py - q.y);
+    R rm, mn;
+    rsqrt_sqrt(fmax(fma(mx, mx, my * my), tiny_of<R>::v), rm, mn);
+    const R e = k.f_obstacle * exp_fast(k.pc, (R(radius) - mn) * k.inv_sigma);  // exp(-(|md| - radius)/sigma)
+    ax = fma(e * rm, mx, ax);
+    ay = fma(e * rm, my, ay);
   }
-  fx = ax * inv_O;
-  fy = ay * inv_O;
+  fx = static_cast<double>(ax) * inv_O;
+  fy = static_cast<double>(ay) * inv_O;
 }
 
-template <typename R> struct lds_layout {
-  using R2 = typename vec2<R>::type;
-  R2 *pos, *vel, *frc, *frj, *goal, *obs;
-  R *gr, *dv, *rad;
-  double *swp;
+struct lds_layout {
+  double2 *pos, *vel, *frc, *frj, *goal, *obs;
+  double *gr, *dv, *rad, *swp;
   int *id, *hasgoal, *dead;
   __device__ lds_layout(char *base, int A, int GA, int G, int O) {
     auto take = [&](size_t bytes) {
@@ -343,36 +354,23 @@ template <typename R> struct lds_layout {
       base += (bytes + 15) & ~size_t(15);
       return p;
     };
-    pos = reinterpret_cast<R2 *>(take(sizeof(R2) * GA));
-    vel = reinterpret_cast<R2 *>(take(sizeof(R2) * GA));
-    frc = reinterpret_cast<R2 *>(take(sizeof(R2) * GA));
-    frj = reinterpret_cast<R2 *>(take(sizeof(R2) * GA));
-    goal = reinterpret_cast<R2 *>(take(sizeof(R2) * A));
-    obs = reinterpret_cast<R2 *>(take(sizeof(R2) * (O > 0 ? O : 1)));
+    pos = reinterpret_cast<double2 *>(take(sizeof(double2) * GA));
+    vel = reinterpret_cast<double2 *>(take(sizeof(double2) * GA));
+    frc = reinterpret_cast<double2 *>(take(sizeof(double2) * GA));
+    frj = reinterpret_cast<double2 *>(take(sizeof(double2) * GA));
+    goal = reinterpret_cast<double2 *>(take(sizeof(double2) * A));
+    obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? O : 1)));
     swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
-    gr = reinterpret_cast<R *>(take(sizeof(R) * A));
-    dv = reinterpret_cast<R *>(take(sizeof(R) * A));
-    rad = reinterpret_cast<R *>(take(sizeof(R) * A));
+    gr = reinterpret_cast<double *>(take(sizeof(double) * A));
+    dv = reinterpret_cast<double *>(take(sizeof(double) * A));
+    rad = reinterpret_cast<double *>(take(sizeof(double) * A));
     id = reinterpret_cast<int *>(take(sizeof(int) * A));
     hasgoal = reinterpret_cast<int *>(take(sizeof(int) * GA));
     dead = reinterpret_cast<int *>(take(sizeof(int) * G));
   }
 };
 
-template <typename R>
-__global__ void __launch_bounds__(WAVE) sfw_social_kernel(const sfw_launch L, const int G) {
-  using R2 = typename vec2<R>::type;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x;
-  const int A = L.A, O = L.O, S = L.S;
-  const int GA = G * A;
-  lds_layout<R> s(smem, A, GA, G, O);
-
-  const int64_t first_local = static_cast<int64_t>(blockIdx.x) * G;  // first sample of this wave
-  // number of real samples in this wave
-  const int64_t remain = L.chunk_count - first_local;
-  const int Gn = remain < G ? static_cast<int>(remain) : G;
-
+template <typename R> __device__ __forceinline__ sfm_consts<R> make_consts(const sfw_launch &L) {
   sfm_consts<R> k;
   k.lambda = R(L.p.sfm_lambda);
   k.gamma = R(L.p.sfm_gamma);
@@ -380,190 +378,123 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel(const sfw_launch L, co
   k.n = R(L.p.sfm_n);
   k.n_prime = R(L.p.sfm_n_prime);
   k.f_social = R(L.p.sfm_force_factor_social);
-  k.f_desired = R(L.p.sfm_force_factor_desired);
-  k.inv_tau = R(1.0 / L.p.sfm_relaxation_time);
   k.f_obstacle = R(L.p.sfm_force_factor_obstacle);
   k.inv_sigma = R(1.0 / L.p.sfm_force_sigma_obstacle);
-  k.dt = R(L.dt);
-  k.rr = R(static_cast<double>(L.p.robot_radius * L.p.robot_radius));  // float product, ref :617
-  const R inv_O = O > 0 ? R(1.0 / O) : R(0);
+  k.f_desired = L.p.sfm_force_factor_desired;
+  k.inv_tau = 1.0 / L.p.sfm_relaxation_time;
+  k.dt = L.dt;
+  k.rr = static_cast<double>(L.p.robot_radius * L.p.robot_radius);  // float product, ref :617
+  return k;
+}
 
-  // ---- stage constants + initial state ----------------------------------
+// One agent slot after the pair pass of a step: integrate the person (or
+// overwrite the robot), contact test, social-work terms, next step's
+// desired+obstacle force.  F = total force on the agent at the pre-step state
+// (for the robot: its social force only).  Returns this slot's social work.
+template <typename R>
+__device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_layout &s, const sfw_robot_step &rs,
+                                             int i, int g, int sl, int O, double inv_O, int robot_id,
+                                             double &px, double &py, double &vx, double &vy, double Fx, double Fy,
+                                             double &nfx, double &nfy) {
+  double work = 0.0;
+  if (i == 0) {
+    // Wr (ref :681-682): robot's social + obstacle force norms at the pre-step state
+    work = fast_norm(Fx, Fy);
+    if (O > 0) {
+      double ox, oy;
+      obstacle_force<R>(k, s.obs, O, inv_O, px, py, s.rad[0], ox, oy);
+      work += fast_norm(ox, oy);
+    }
+    px = rs.x;   // ref :600
+    py = rs.y;
+    vx = rs.vx;  // ref :604 (robot-local twist)
+    vy = rs.vy;
+    nfx = 0.0;
+    nfy = 0.0;
+  } else {
+    // lightsfm updatePosition, non-teleoperated branch
+    vx = fma(Fx, k.dt, vx);
+    vy = fma(Fy, k.dt, vy);
+    const double dv = s.dv[i];
+    double rsp, sp;
+    sfwm::rsqrt_sqrt(fmax(fma(vx, vx, vy * vy), 1e-300), rsp, sp);
+    if (sp > dv) {
+      const double sc = dv * rsp;  // normalize() then *= desiredVelocity
+      vx *= sc;
+      vy *= sc;
+    }
+    px = fma(vx, k.dt, px);
+    py = fma(vy, k.dt, py);
+    const double2 gl = s.goal[i];
+    const double grad = s.gr[i];
+    int hg = s.hasgoal[sl];
+    if (hg) {
+      const double ex = gl.x - px, ey = gl.y - py;
+      if (fast_norm(ex, ey) <= grad) hg = 0;  // goal reached: pop
+      s.hasgoal[sl] = hg;
+    }
+    // dynamic collision with the robot's post-step pose (ref :613-627)
+    const double cx = rs.x - px, cy = rs.y - py;
+    if (cx * cx + cy * cy <= k.rr) s.dead[g] = 2;
+    // Wp (ref :692-699): force the post-step robot alone exerts on this person
+    if (s.id[i] != robot_id) {
+      R qx, qy;
+      pair_force_state<R>(k, px, py, vx, vy, rs.x, rs.y, rs.vx, rs.vy, qx, qy);
+      work = fast_norm(static_cast<double>(qx), static_cast<double>(qy));
+    }
+    // desired + obstacle force at the new state = next step's starting force
+    desired_force<R>(k, px, py, vx, vy, hg != 0, gl.x, gl.y, grad, dv, nfx, nfy);
+    if (O > 0) {
+      double ox, oy;
+      obstacle_force<R>(k, s.obs, O, inv_O, px, py, s.rad[i], ox, oy);
+      nfx += ox;
+      nfy += oy;
+    }
+  }
+  return work;
+}
+
+// Stage the per-launch constants and the initial agent state into LDS; returns
+// false when every sample of this wave was already rejected by K1.
+__device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout &s, int lane, int G, int Gn,
+                                           int64_t first_local) {
+  const int A = L.A, O = L.O;
   for (int i = lane; i < A; i += WAVE) {
     const sfw_agent_const c = L.agent_c[i];
-    s.goal[i] = R2{R(c.goal_x), R(c.goal_y)};
-    s.gr[i] = R(c.goal_radius);
-    s.dv[i] = R(c.desired_velocity);
-    s.rad[i] = R(c.radius);
+    s.goal[i] = double2{c.goal_x, c.goal_y};
+    s.gr[i] = c.goal_radius;
+    s.dv[i] = c.desired_velocity;
+    s.rad[i] = c.radius;
     s.id[i] = c.id;
   }
-  for (int o = lane; o < O; o += WAVE) s.obs[o] = R2{R(L.obstacles[2 * o]), R(L.obstacles[2 * o + 1])};
+  for (int o = lane; o < O; o += WAVE) s.obs[o] = double2{L.obstacles[2 * o], L.obstacles[2 * o + 1]};
   if (lane < G) {
     int dead = 1;
     if (lane < Gn) dead = (L.status[L.chunk_begin + first_local + lane] != SFW_ST_VALID);
     s.dead[lane] = dead;
   }
   __syncthreads();
-  {
-    bool any_live = false;
-    for (int g = 0; g < G; ++g) any_live |= (s.dead[g] == 0);
-    if (!any_live) return;  // every sample of this wave was rejected by K1
-  }
-  for (int sl = lane; sl < GA; sl += WAVE) {
-    const int g = (G == 1) ? 0 : sl / A;
-    const int i = sl - g * A;
-    const R px = R(L.agent_pos[2 * i]), py = R(L.agent_pos[2 * i + 1]);
-    const R vx = R(L.agent_vel[2 * i]), vy = R(L.agent_vel[2 * i + 1]);
-    const int hg = L.agent_c[i].has_goal;
-    s.pos[sl] = R2{px, py};
-    s.vel[sl] = R2{vx, vy};
-    s.hasgoal[sl] = hg;
-    R fx = R(0), fy = R(0);
-    if (i != 0) {
-      const R2 gl = s.goal[i];
-      desired_force<R>(k, px, py, vx, vy, hg != 0, gl.x, gl.y, s.gr[i], s.dv[i], fx, fy);
-      if (O > 0) {
-        R ox, oy;
-        obstacle_force<R, R2>(k, s.obs, O, inv_O, px, py, s.rad[i], ox, oy);
-        fx += ox;
-        fy += oy;
-      }
-    }
-    s.frc[sl] = R2{fx, fy};
-    s.frj[sl] = R2{R(0), R(0)};
-  }
-  __syncthreads();
+  bool any_live = false;
+  for (int g = 0; g < G; ++g) any_live |= (s.dead[g] == 0);
+  return any_live;
+}
 
-  const int P = A * (A - 1) / 2;  // unordered pairs per sample
-  const int GP = G * P;
-  const float invA = 1.0f / static_cast<float>(A);
-  const float invP = P > 0 ? 1.0f / static_cast<float>(P) : 0.0f;
-  const int robot_id = s.id[0];
-  double sw_acc = 0.0;  // this lane's share of the social work (one fixed sample per lane)
-
-  for (int step = 0; step < S; ++step) {
-    // ---- pair pass: social forces at the pre-step state ------------------
-    // Items are the unordered pairs of every sample, flattened over the lanes:
-    // u in [0,P) -> row = u / A, i = u % A, j = (i + row + 1) % A  (half ring).
-    for (int t = lane; t < GP; t += WAVE) {
-      int g = 0, u = t;
-      if (G > 1) {
-        g = static_cast<int>(static_cast<float>(t) * invP);
-        u = t - g * P;
-        if (u < 0) { --g; u += P; }
-        if (u >= P) { ++g; u -= P; }
-      }
-      int row = static_cast<int>(static_cast<float>(u) * invA);
-      int i = u - row * A;
-      if (i < 0) { --row; i += A; }
-      if (i >= A) { ++row; i -= A; }
-      int j = i + row + 1;
-      if (j >= A) j -= A;
-      const int si = g * A + i, sj = g * A + j;
-      const R2 pi = s.pos[si], pj = s.pos[sj], vi = s.vel[si], vj = s.vel[sj];
-      R fx, fy;
-      pair_force<R>(k, pi.x, pi.y, vi.x, vi.y, pj.x, pj.y, vj.x, vj.y, fx, fy);
-      // Two accumulators per agent: what it receives as the pair's `i` and as its
-      // `j`.  Each one then sums its contributions in item order whatever the
-      // sample's position inside the wave, so a sample's result does not depend
-      // on how samples are packed into waves (or sharded over GPUs).
-      atomicAdd(&s.frc[si].x, fx);
-      atomicAdd(&s.frc[si].y, fy);
-      atomicAdd(&s.frj[sj].x, -fx);
-      atomicAdd(&s.frj[sj].y, -fy);
-    }
-    __syncthreads();
-
-    // ---- per-agent pass: integrate, collide, social work, next forces ----
-    for (int sl = lane; sl < GA; sl += WAVE) {
-      const int g = (G == 1) ? 0 : sl / A;
-      const int i = sl - g * A;
-      if (s.dead[g]) continue;
-      const sfw_robot_step rs = L.rstep[static_cast<int64_t>(step) * L.rstep_stride + first_local + g];
-      const R rx = R(rs.x), ry = R(rs.y), rvx = R(rs.vx), rvy = R(rs.vy);
-      R2 F = s.frc[sl];
-      {
-        const R2 Fj = s.frj[sl];
-        F.x += Fj.x;
-        F.y += Fj.y;
-        s.frj[sl] = R2{R(0), R(0)};
-      }
-      if (i == 0) {
-        // Wr (ref :681-682): robot's social + obstacle force norms at the pre-step state
-        R wr = m_sqrt<R>(F.x * F.x + F.y * F.y);
-        if (O > 0) {
-          const R2 p0 = s.pos[sl];
-          R ox, oy;
-          obstacle_force<R, R2>(k, s.obs, O, inv_O, p0.x, p0.y, s.rad[0], ox, oy);
-          wr += m_sqrt<R>(ox * ox + oy * oy);
-        }
-        sw_acc += static_cast<double>(wr);
-        s.pos[sl] = R2{rx, ry};      // ref :600
-        s.vel[sl] = R2{rvx, rvy};    // ref :604 (robot-local twist)
-        s.frc[sl] = R2{R(0), R(0)};
-      } else {
-        // lightsfm updatePosition, non-teleoperated branch
-        const R2 p0 = s.pos[sl], v0 = s.vel[sl];
-        R vx = v0.x + F.x * k.dt, vy = v0.y + F.y * k.dt;
-        const R dv = s.dv[i];
-        const R sp = m_sqrt<R>(vx * vx + vy * vy);
-        if (sp > dv) {
-          const R sc = dv / sp;  // normalize() then *= desiredVelocity
-          vx *= sc;
-          vy *= sc;
-        }
-        const R px = p0.x + vx * k.dt, py = p0.y + vy * k.dt;
-        const R2 gl = s.goal[i];
-        const R grad = s.gr[i];
-        int hg = s.hasgoal[sl];
-        if (hg) {
-          const R ex = gl.x - px, ey = gl.y - py;
-          if (m_sqrt<R>(ex * ex + ey * ey) <= grad) hg = 0;  // goal reached: pop
-        }
-        // dynamic collision with the robot's post-step pose (ref :613-627)
-        const R cx = rx - px, cy = ry - py;
-        if (cx * cx + cy * cy <= k.rr) s.dead[g] = 2;
-        // Wp (ref :692-699): force the post-step robot alone exerts on this person
-        if (s.id[i] != robot_id) {
-          R qx, qy;
-          pair_force<R>(k, px, py, vx, vy, rx, ry, rvx, rvy, qx, qy);
-          sw_acc += static_cast<double>(m_sqrt<R>(qx * qx + qy * qy));
-        }
-        // desired + obstacle force at the new state = next step's starting force
-        R fx, fy;
-        desired_force<R>(k, px, py, vx, vy, hg != 0, gl.x, gl.y, grad, dv, fx, fy);
-        if (O > 0) {
-          R ox, oy;
-          obstacle_force<R, R2>(k, s.obs, O, inv_O, px, py, s.rad[i], ox, oy);
-          fx += ox;
-          fy += oy;
-        }
-        s.pos[sl] = R2{px, py};
-        s.vel[sl] = R2{vx, vy};
-        s.frc[sl] = R2{fx, fy};
-        s.hasgoal[sl] = hg;
-      }
-    }
-    __syncthreads();
-    bool any_live = false;
-    for (int g = 0; g < G; ++g) any_live |= (s.dead[g] == 0);
-    if (!any_live) break;
-  }
-
-  // ---- per-sample reduction of the social work, in lane order -----------
-  // A lane owns slots lane, lane+64, ... which all belong to one sample when
-  // G == 1, and exactly one slot when G > 1 (GA <= 64).
+// Write the per-sample results: cost = base + w_s * social_work (ref :663-667).
+__device__ __forceinline__ void finish_wave(const sfw_launch &L, const lds_layout &s, int lane, int G, int Gn,
+                                            int GA, int64_t first_local, double sw_acc) {
+  const int A = L.A;
   if (G == 1) {
     double v = sw_acc;
     for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
     if (lane == 0) {
       const int64_t t = L.chunk_begin + first_local;
       const int d = s.dead[0];
-      if (d == 0) L.costs[t] = L.base_cost[t] + L.p.social_weight * v;  // ref :663-667
+      if (d == 0) L.costs[t] = L.base_cost[t] + L.p.social_weight * v;
       else if (d == 2) { L.costs[t] = SFW_COST_INVALID; L.status[t] = SFW_ST_INVALID; }
     }
   } else {
-    if (lane < GA) s.swp[lane] = sw_acc;
+    // G > 1: every lane owns slots of possibly different samples; per-slot sums
+    // were accumulated into swp[] and are added per sample in agent order.
     __syncthreads();
     if (lane < Gn) {
       double v = 0.0;
@@ -574,6 +505,215 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel(const sfw_launch L, co
       else if (d == 2) { L.costs[t] = SFW_COST_INVALID; L.status[t] = SFW_ST_INVALID; }
     }
   }
+  (void)GA;
+}
+
+// ---------------------------------------------------------------------------
+// K2, register-resident form: every lane owns NS agent slots (slot = r*64+lane,
+// slot -> (sample g, agent i)) whose state and force accumulator stay in VGPRs
+// for the whole rollout; LDS holds the copy the partners read.  The unordered
+// pairs are walked as a half ring: in row k every agent i meets
+// j = (i + k + 1) mod A, so within a row each agent is `i` once and `j` once:
+// the i-side force accumulates in registers, the j-side goes through one LDS
+// atomic whose addresses are all distinct within the instruction.
+// ---------------------------------------------------------------------------
+template <typename R, int NS>
+__global__ void __launch_bounds__(WAVE) sfw_social_kernel(const sfw_launch L, const int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int A = L.A, O = L.O, S = L.S;
+  const int GA = G * A;
+  const lds_layout s(smem, A, GA, G, O);
+  const int64_t first_local = static_cast<int64_t>(blockIdx.x) * G;
+  const int64_t remain = L.chunk_count - first_local;
+  const int Gn = remain < G ? static_cast<int>(remain) : G;
+  const sfm_consts<R> k = make_consts<R>(L);
+  const double inv_O = O > 0 ? 1.0 / O : 0.0;
+  if (!stage_wave(L, s, lane, G, Gn, first_local)) return;
+
+  // ---- this lane's slots --------------------------------------------------
+  int sl_[NS], g_[NS], i_[NS];
+  bool ok_[NS];
+  double px[NS], py[NS], vx[NS], vy[NS], fx[NS], fy[NS], sw[NS];
+#pragma unroll
+  for (int r = 0; r < NS; ++r) {
+    const int sl = r * WAVE + lane;
+    ok_[r] = sl < GA;
+    const int slc = ok_[r] ? sl : 0;
+    g_[r] = (G == 1) ? 0 : slc / A;
+    i_[r] = slc - g_[r] * A;
+    sl_[r] = slc;
+    const int i = i_[r];
+    px[r] = L.agent_pos[2 * i];
+    py[r] = L.agent_pos[2 * i + 1];
+    vx[r] = L.agent_vel[2 * i];
+    vy[r] = L.agent_vel[2 * i + 1];
+    fx[r] = fy[r] = sw[r] = 0.0;
+    if (ok_[r]) {
+      const int hg = L.agent_c[i].has_goal;
+      s.pos[sl] = double2{px[r], py[r]};
+      s.vel[sl] = double2{vx[r], vy[r]};
+      s.frj[sl] = double2{0.0, 0.0};
+      s.hasgoal[sl] = hg;
+      if (i != 0) {
+        const double2 gl = s.goal[i];
+        desired_force<R>(k, px[r], py[r], vx[r], vy[r], hg != 0, gl.x, gl.y, s.gr[i], s.dv[i], fx[r], fy[r]);
+        if (O > 0) {
+          double ox, oy;
+          obstacle_force<R>(k, s.obs, O, inv_O, px[r], py[r], s.rad[i], ox, oy);
+          fx[r] += ox;
+          fy[r] += oy;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int rows = A / 2;            // half ring; for even A the last row is half length
+  const bool even = (A & 1) == 0;
+  const int robot_id = s.id[0];
+
+  for (int step = 0; step < S; ++step) {
+    // ---- pair pass: social forces at the pre-step state -------------------
+    for (int row = 0; row < rows; ++row) {
+      const bool half = even && (row == rows - 1);
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        const int i = i_[r];
+        if (ok_[r] && !(half && i >= rows)) {
+          int j = i + row + 1;
+          j = (j >= A) ? j - A : j;
+          const int sj = sl_[r] - i + j;
+          const double2 pj = s.pos[sj], vj = s.vel[sj];
+          R qx, qy;
+          pair_force_state<R>(k, px[r], py[r], vx[r], vy[r], pj.x, pj.y, vj.x, vj.y, qx, qy);
+          fx[r] += static_cast<double>(qx);
+          fy[r] += static_cast<double>(qy);
+          atomicAdd(&s.frj[sj].x, -static_cast<double>(qx));
+          atomicAdd(&s.frj[sj].y, -static_cast<double>(qy));
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- per-agent pass ---------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+      if (ok_[r] && s.dead[g_[r]] == 0) {
+        const int sl = sl_[r];
+        const sfw_robot_step rs = L.rstep[static_cast<int64_t>(step) * L.rstep_stride + first_local + g_[r]];
+        const double2 Fj = s.frj[sl];
+        double nfx, nfy;
+        sw[r] += agent_step<R>(k, s, rs, i_[r], g_[r], sl, O, inv_O, robot_id, px[r], py[r], vx[r], vy[r],
+                               fx[r] + Fj.x, fy[r] + Fj.y, nfx, nfy);
+        fx[r] = nfx;
+        fy[r] = nfy;
+        s.pos[sl] = double2{px[r], py[r]};
+        s.vel[sl] = double2{vx[r], vy[r]};
+        s.frj[sl] = double2{0.0, 0.0};
+      }
+    }
+    __syncthreads();
+    bool any_live = false;
+    for (int g = 0; g < G; ++g) any_live |= (s.dead[g] == 0);
+    if (!any_live) break;
+  }
+
+  double sw_acc = 0.0;
+#pragma unroll
+  for (int r = 0; r < NS; ++r) {
+    if (G == 1) sw_acc += ok_[r] ? sw[r] : 0.0;
+    else if (ok_[r]) s.swp[sl_[r]] = sw[r];
+  }
+  finish_wave(L, s, lane, G, Gn, GA, first_local, sw_acc);
+}
+
+// ---------------------------------------------------------------------------
+// K2, flat form (one sample per wave): the A(A-1)/2 unordered pairs are
+// flattened over the 64 lanes, u -> row = u / A, i = u % A, j = (i + row + 1) % A,
+// so lane utilisation is ~100 % for any A (the register-resident form idles
+// 64*NS - A lanes).  All agent state lives in LDS; both sides of a pair go through
+// LDS atomics, into two accumulators per agent (received "as i" / "as j") so that
+// each accumulator's summation order is a function of u only.
+// ---------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(WAVE) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  (void)G_unused;
+  const int lane = threadIdx.x;
+  const int A = L.A, O = L.O, S = L.S;
+  const lds_layout s(smem, A, A, 1, O);
+  const int64_t first_local = blockIdx.x;
+  const sfm_consts<R> k = make_consts<R>(L);
+  const double inv_O = O > 0 ? 1.0 / O : 0.0;
+  if (!stage_wave(L, s, lane, 1, 1, first_local)) return;
+
+  for (int sl = lane; sl < A; sl += WAVE) {
+    const double px = L.agent_pos[2 * sl], py = L.agent_pos[2 * sl + 1];
+    const double vx = L.agent_vel[2 * sl], vy = L.agent_vel[2 * sl + 1];
+    const int hg = L.agent_c[sl].has_goal;
+    s.pos[sl] = double2{px, py};
+    s.vel[sl] = double2{vx, vy};
+    s.hasgoal[sl] = hg;
+    s.swp[sl] = 0.0;
+    double fx = 0.0, fy = 0.0;
+    if (sl != 0) {
+      const double2 gl = s.goal[sl];
+      desired_force<R>(k, px, py, vx, vy, hg != 0, gl.x, gl.y, s.gr[sl], s.dv[sl], fx, fy);
+      if (O > 0) {
+        double ox, oy;
+        obstacle_force<R>(k, s.obs, O, inv_O, px, py, s.rad[sl], ox, oy);
+        fx += ox;
+        fy += oy;
+      }
+    }
+    s.frc[sl] = double2{fx, fy};
+    s.frj[sl] = double2{0.0, 0.0};
+  }
+  __syncthreads();
+
+  const int P = A * (A - 1) / 2;  // unordered pairs
+  const int robot_id = s.id[0];
+  // this lane's first item and the per-iteration stride 64 = dq*A + dr
+  const int dq = WAVE / A, dr = WAVE - dq * A;
+  const int row0 = lane / A, i0 = lane - row0 * A;
+
+  for (int step = 0; step < S; ++step) {
+    int row = row0, i = i0;
+    for (int u = lane; u < P; u += WAVE) {
+      int j = i + row + 1;
+      j = (j >= A) ? j - A : j;
+      const double2 pi = s.pos[i], pj = s.pos[j], vi = s.vel[i], vj = s.vel[j];
+      R qx, qy;
+      pair_force_state<R>(k, pi.x, pi.y, vi.x, vi.y, pj.x, pj.y, vj.x, vj.y, qx, qy);
+      atomicAdd(&s.frc[i].x, static_cast<double>(qx));
+      atomicAdd(&s.frc[i].y, static_cast<double>(qy));
+      atomicAdd(&s.frj[j].x, -static_cast<double>(qx));
+      atomicAdd(&s.frj[j].y, -static_cast<double>(qy));
+      i += dr;
+      row += dq;
+      if (i >= A) { i -= A; ++row; }
+    }
+    __syncthreads();
+    const sfw_robot_step rs = L.rstep[static_cast<int64_t>(step) * L.rstep_stride + first_local];
+    for (int sl = lane; sl < A; sl += WAVE) {
+      const double2 Fi = s.frc[sl], Fj = s.frj[sl];
+      double2 p = s.pos[sl], v = s.vel[sl];
+      double nfx, nfy;
+      const double w = agent_step<R>(k, s, rs, sl, 0, sl, O, inv_O, robot_id, p.x, p.y, v.x, v.y, Fi.x + Fj.x,
+                                     Fi.y + Fj.y, nfx, nfy);
+      s.swp[sl] += w;
+      s.pos[sl] = p;
+      s.vel[sl] = v;
+      s.frc[sl] = double2{nfx, nfy};
+      s.frj[sl] = double2{0.0, 0.0};
+    }
+    __syncthreads();
+    if (s.dead[0] != 0) break;
+  }
+  double sw_acc = 0.0;
+  for (int sl = lane; sl < A; sl += WAVE) sw_acc += s.swp[sl];
+  finish_wave(L, s, lane, 1, 1, A, first_local, sw_acc);
 }
 
 // ===========================================================================
@@ -663,24 +803,48 @@ sfw_argmin_stage2(const sfw_sel *partials, int n, sfw_sel *out) {
 // ===========================================================================
 // launchers
 // ===========================================================================
-int sfw_samples_per_wave(int A) {
-  if (A <= 0) return 1;
-  int g = WAVE / A;
-  return g < 1 ? 1 : g;
+
+
+// How one wave is organised for A agents (measured on MI355X):
+//   reg  NS=1 : G = floor(64/A) samples per wave, lanes used G*A/64, ~141 VALU/pair
+//   reg  NS=2 : one sample, lanes used A/128 (64 < A <= 128), slightly lower occupancy
+//   flat      : one sample, ~100 % of the lanes but ~20 % more instructions per pair
+// pick the largest utilisation x efficiency.
+struct wave_plan { int G; int ns; bool flat; };
+static wave_plan plan_for(int A) {
+  wave_plan best{1, 0, true};
+  if (A <= 0) return wave_plan{1, 1, false};
+  const int P = A * (A - 1) / 2;
+  double best_score = P > 0 ? 0.82 * P / (64.0 * ((P + WAVE - 1) / WAVE)) : 0.0;
+  if (A <= WAVE) {
+    const int g = WAVE / A < 64 ? WAVE / A : 64;
+    const double sc = 1.0 * g * A / WAVE;
+    if (sc >= best_score) { best_score = sc; best = wave_plan{g, 1, false}; }
+  } else if (A <= 2 * WAVE) {
+    const double sc = 0.95 * A / (2.0 * WAVE);
+    if (sc >= best_score) { best_score = sc; best = wave_plan{1, 2, false}; }
+  }
+  if (const char *e = getenv("SFW_FORCE_FLAT")) {  // tuning overrides
+    if (atoi(e) == 1 && A >= 2) best = wave_plan{1, 0, true};
+    if (atoi(e) == 0 && A <= 2 * WAVE) best = (A <= WAVE) ? wave_plan{WAVE / A, 1, false} : wave_plan{1, 2, false};
+  }
+  return best;
 }
 
+int sfw_samples_per_wave(int A) { return plan_for(A).G; }
+
 size_t sfw_social_lds_bytes(int A, int O, int precision) {
-  const size_t r = precision == SFW_PRECISION_F32 ? 4 : 8;
+  (void)precision;
   const int G = sfw_samples_per_wave(A);
   const size_t GA = static_cast<size_t>(G) * A;
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
   size_t n = 0;
-  n += 4 * up(2 * r * GA);                 // pos, vel, frc, frj
-  n += up(2 * r * A);                      // goal
-  n += up(2 * r * (O > 0 ? O : 1));        // obs
-  n += up(8 * GA);                         // swp
-  n += 3 * up(r * A);                      // gr, dv, rad
-  n += up(4 * A) + up(4 * GA) + up(4 * G); // id, hasgoal, dead
+  n += 4 * up(16 * GA);                     // pos, vel, frc, frj
+  n += up(16 * A);                          // goal
+  n += up(16 * (O > 0 ? O : 1));            // obs
+  n += up(8 * GA);                          // swp
+  n += 3 * up(8 * A);                       // gr, dv, rad
+  n += up(4 * A) + up(4 * GA) + up(4 * G);  // id, hasgoal, dead
   return n;
 }
 
@@ -705,28 +869,31 @@ hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream) {
-  if (L.chunk_count <= 0 || L.A <= 0) return hipSuccess;
-  const int G = sfw_samples_per_wave(L.A);
-  const unsigned grid = static_cast<unsigned>((L.chunk_count + G - 1) / G);
+template <typename K> static hipError_t launch_social_as(K kernel, const sfw_launch &L, int G, unsigned grid,
+                                                          size_t lds, hipStream_t stream) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVE), lds, stream, L, G);
+  return hipGetLastError();
+}
+
+template <typename R> static hipError_t launch_social_typed(const sfw_launch &L, hipStream_t stream) {
+  const wave_plan pl = plan_for(L.A);
+  const unsigned grid = static_cast<unsigned>((L.chunk_count + pl.G - 1) / pl.G);
   const size_t lds = sfw_social_lds_bytes(L.A, L.O, L.p.precision);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  if (L.p.precision == SFW_PRECISION_F32) {
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sfw_social_kernel<float>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(sfw_social_kernel<float>, dim3(grid), dim3(WAVE), lds, stream, L, G);
-  } else {
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sfw_social_kernel<double>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(sfw_social_kernel<double>, dim3(grid), dim3(WAVE), lds, stream, L, G);
-  }
-  return hipGetLastError();
+  if (pl.flat) return launch_social_as(sfw_social_kernel_flat<R>, L, 1, grid, lds, stream);
+  if (pl.ns == 1) return launch_social_as(sfw_social_kernel<R, 1>, L, pl.G, grid, lds, stream);
+  return launch_social_as(sfw_social_kernel<R, 2>, L, pl.G, grid, lds, stream);
+}
+
+hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream) {
+  if (L.chunk_count <= 0 || L.A <= 0) return hipSuccess;
+  if (L.p.precision == SFW_PRECISION_F32) return launch_social_typed<float>(L, stream);
+  return launch_social_typed<double>(L, stream);
 }
 
 int64_t sfw_argmin_partials(int64_t T) {
