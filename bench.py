@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (target-config) measurement")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (gloo: CPU tensors; lets several ranks share one GPU in tests)")
     ap.add_argument("--grid", default=None, help="override the sample grid, e.g. 512x512 (experiments only)")
     ap.add_argument("--verify", action="store_true", help="check the GPU result against the oracle on a sample subset")
     return ap.parse_args()
@@ -150,7 +152,7 @@ def run_single_config(workload_name, precision, steps, warmup, dist_ctx):
     def one_step():
         best, key = job.step()
         if dist is not None:  # single all-reduce(min): every rank fills its own row, +inf elsewhere
-            wr, wk, _ = multi_gpu.exchange_best(key, dist, rank, world, device=f"cuda:{device}")
+            wr, wk, _ = multi_gpu.exchange_best(key, dist, rank, world, device=dist_ctx["coll_device"])
             state["win"] = (wr, wk)
         return best, key
 
@@ -173,10 +175,10 @@ def run_single_config(workload_name, precision, steps, warmup, dist_ctx):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dist_ctx["coll_device"])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([float(job.n_scored)], dtype=torch.float64, device=f"cuda:{device}")
+        tot = torch.tensor([float(job.n_scored)], dtype=torch.float64, device=dist_ctx["coll_device"])
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         n_scored_total = int(tot.item())
         win_rank, win_key = state["win"]
@@ -243,10 +245,19 @@ def main():
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        n_dev = torch.cuda.device_count()
+        if args.backend == "nccl":
+            if local_rank >= n_dev:
+                raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible")
+            torch.cuda.set_device(local_rank)
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            local_rank = local_rank % n_dev
+            torch.cuda.set_device(local_rank)
+            dist_mod.init_process_group(backend="gloo")
         dist = dist_mod
-    ctx = {"rank": rank, "world": world, "device": local_rank, "dist": dist}
+    ctx = {"rank": rank, "world": world, "device": local_rank, "dist": dist,
+           "coll_device": f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"}
 
     res = run_single_config(args.workload, args.precision, args.steps, args.warmup, ctx)
     job = res["job"]
@@ -279,6 +290,13 @@ def main():
                     "index": res["best"]["index"], "n_valid": res["best"]["n_valid"]},
         "roofline": roofline_for(job, res["k2_ms"], args.precision),
     }
+    if world > 1:
+        from social_force_window_planner_amd import multi_gpu
+
+        gvx, gvth, gidx = multi_gpu.cmd_from_key(res["global_key"], len(job.ang), job.scene.linvels, job.ang)
+        out["global_cmd_vel"] = {"vx": gvx, "vtheta": gvth, "index": gidx,
+                                 "cost": res["global_key"][0] if res["global_key"] else -1.0,
+                                 "winner_rank": res["winner_rank"]}
     if rank == 0 and world == 1:
         if args.verify:
             from oracle.sfw_oracle import OracleScorer

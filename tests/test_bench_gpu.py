@@ -1,0 +1,65 @@
+"""bench.py contract: one JSON line with the required keys (N=1), and the N>1
+code path (row sharding + all-reduce(min) exchange) exercised with two ranks
+sharing the one visible GPU over gloo."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--verify"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["higher_is_better"] is True and "cfg2" in d["config"]["workload"]
+    assert d["value"] > 1e6  # north-star floor, on the N=20 configuration
+    rf = d["roofline"]
+    assert rf["bound"] == "valu" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["hbm"]["unit"] == "GB/s" and rf["hbm"]["frac"] < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["all_cores"]["cores"] >= 1
+    assert d["verify"]["same_invalid_set"] and d["verify"]["max_rel_err"] <= 1e-9
+    assert d["value"] / cb["value"] > 100  # sanity: the GPU path is not the CPU path
+
+
+def test_two_ranks_on_one_gpu_over_gloo():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--no-cpu-baseline", "--no-extra"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d2 = _last_json(r.stdout)
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["config"]["samples_per_gpu"] == 16384
+    # the same 256x128 grid scored by one process selects the same command
+    r1 = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--grid", "256x128",
+                         "--no-cpu-baseline", "--no-extra"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = _last_json(r1.stdout)
+    assert d2["global_cmd_vel"]["index"] == d1["cmd_vel"]["index"]
+    assert d2["global_cmd_vel"]["vx"] == d1["cmd_vel"]["vx"] and d2["global_cmd_vel"]["vtheta"] == d1["cmd_vel"]["vtheta"]
+    assert d2["global_cmd_vel"]["cost"] == d1["cmd_vel"]["cost"]
