@@ -247,7 +247,7 @@ template <> struct tiny_of<float> { static constexpr float v = 1e-30f; };
 // Per-launch social-force constants in the force type.
 template <typename R> struct sfm_consts {
   sfwm::poly_consts pc;
-  R lambda, gamma, inv_gamma, n, n_prime, f_social;
+  R lambda, gamma, neg_inv_gamma, n2, n_prime2, f_social;
   R f_obstacle, inv_sigma;
   double f_desired, inv_tau, dt, rr;
 };
@@ -279,11 +279,11 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   const R sn = fma(ix, uy, -(iy * ux));  // |I| sin(theta)
   const R cs = fma(ix, ux, iy * uy);     // |I| cos(theta)
   const R theta = atan2_abs(k.pc, fabs(sn), cs);
-  const R a = -dn * rl * k.inv_gamma;    // -|diff| / B
-  const R bt = k.gamma * il * theta;     // B * |theta|
-  const R sv = k.n_prime * bt, sa = k.n * bt;
-  const R ev = exp_fast(k.pc, fma(-sv, sv, a));
-  R ea = exp_fast(k.pc, fma(-sa, sa, a));
+  const R a = dn * rl * k.neg_inv_gamma;  // -|diff| / B
+  const R bt = k.gamma * il * theta;      // B * |theta|
+  const R bt2 = bt * bt;
+  const R ev = exp_fast(k.pc, fma(-k.n_prime2, bt2, a));
+  R ea = exp_fast(k.pc, fma(-k.n2, bt2, a));
   ea = cw > 0.0 ? ea : (cw < 0.0 ? -ea : R(0));  // sign(theta) * exp(...)
   const R sc = rl * k.f_social;
   const R gx = ix * sc, gy = iy * sc;    // Fs * Ihat
@@ -374,9 +374,9 @@ template <typename R> __device__ __forceinline__ sfm_consts<R> make_consts(const
   sfm_consts<R> k;
   k.lambda = R(L.p.sfm_lambda);
   k.gamma = R(L.p.sfm_gamma);
-  k.inv_gamma = R(1.0 / L.p.sfm_gamma);
-  k.n = R(L.p.sfm_n);
-  k.n_prime = R(L.p.sfm_n_prime);
+  k.neg_inv_gamma = R(-1.0 / L.p.sfm_gamma);
+  k.n2 = R(L.p.sfm_n * L.p.sfm_n);
+  k.n_prime2 = R(L.p.sfm_n_prime * L.p.sfm_n_prime);
   k.f_social = R(L.p.sfm_force_factor_social);
   k.f_obstacle = R(L.p.sfm_force_factor_obstacle);
   k.inv_sigma = R(1.0 / L.p.sfm_force_sigma_obstacle);

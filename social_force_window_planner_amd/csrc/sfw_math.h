@@ -10,18 +10,17 @@
 
 namespace sfwm {
 
-// atan(q) = q * P(q*q), q in [0,1]; max abs err 5.6e-15
-__device__ constexpr double kAtanP[17] = {
-    9.99999999999981348e-01,  -3.33333333325527892e-01, 1.99999999358193709e-01,  -1.42857120457493492e-01,
-    1.11110683421310363e-01,  -9.09040046372013300e-02, 7.68823292769246491e-02,  -6.64350567821361121e-02,
-    5.78548561483468726e-02,  -4.95689849024251034e-02, 4.01396125667346226e-02,  -2.90889119465990650e-02,
-    1.77171911227863993e-02,  -8.46465692515396828e-03, 2.91643949953273836e-03,  -6.36404154247438851e-04,
-    6.55251344172218128e-05};
-// exp(r), |r| <= ln2/2; max rel err 1.9e-15
-__device__ constexpr double kExpP[11] = {
-    1.00000000000000044e+00, 1.00000000000000533e+00, 4.99999999999804712e-01, 1.66666666665838487e-01,
-    4.16666666805781197e-02, 8.33333337440901947e-03, 1.38888853632852804e-03, 1.98411846695697449e-04,
-    2.48051922108969186e-05, 2.76343033983400868e-06, 2.63067990309652005e-07};
+// atan(q) = q * P(q*q), q in [0,1]; max abs err 3.0e-14
+__device__ constexpr double kAtanP[16] = {
+    9.99999999999944933e-01, -3.33333333306710444e-01, 1.99999997789646333e-01, -1.42857068890334782e-01,
+    1.11109791772467159e-01, -9.08946625885427295e-02, 7.68179614371398145e-02, -6.61281542712686132e-02,
+    5.68091358338733698e-02, -4.69734484941000119e-02, 3.54058579341653967e-02, -2.27526081143878400e-02,
+    1.15690371021628380e-02, -4.25852928310632706e-03, 9.93382185697555542e-04, -1.09195709228515625e-04};
+// exp(r), |r| <= ln2/2; max rel err 1.8e-14
+__device__ constexpr double kExpP[10] = {
+    1.00000000000001421e+00, 1.00000000000000777e+00, 4.99999999994189259e-01, 1.66666666665346158e-01,
+    4.16666670498183830e-02, 8.33333339452756693e-03, 1.38888004009164279e-03, 1.98411575417668925e-04,
+    2.48850574964862367e-05, 2.76457905540610794e-06};
 // float atan(q) = q * P(q*q); max abs err 6.4e-8
 __device__ constexpr float kAtanPf[8] = {9.999998820e-01f, -3.333181266e-01f, 1.996696183e-01f, -1.400329018e-01f,
                                          9.868865458e-02f, -5.882975314e-02f, 2.378051860e-02f, -4.559791986e-03f};
@@ -38,29 +37,27 @@ __device__ __forceinline__ double sgpr_const(double c) {
   return c;
 }
 struct poly_consts {
-  double at[17], ex[11];
+  double at[16], ex[10];
   __device__ __forceinline__ poly_consts() {
 #pragma unroll
-    for (int n = 0; n < 17; ++n) at[n] = sgpr_const(kAtanP[n]);
+    for (int n = 0; n < 16; ++n) at[n] = sgpr_const(kAtanP[n]);
 #pragma unroll
-    for (int n = 0; n < 11; ++n) ex[n] = sgpr_const(kExpP[n]);
+    for (int n = 0; n < 10; ++n) ex[n] = sgpr_const(kExpP[n]);
   }
 };
 // v_rsq_f64 / v_rcp_f64 deliver ~23 good bits; one Newton step gives ~46.
 // x must be > 0 and finite (callers clamp with fmax).
 __device__ __forceinline__ void rsqrt_sqrt(double x, double &rs, double &sq) {
   const double y = __builtin_amdgcn_rsq(x);
-  const double g = x * y;             // ~sqrt(x)
-  const double h = 0.5 * y;           // ~1/(2 sqrt(x))
-  const double r = fma(-h, g, 0.5);   // residual
-  sq = fma(g, r, g);
-  const double h2 = fma(h, r, h);
-  rs = h2 + h2;
+  const double h = 0.5 * x;
+  const double r = fma(-h, y * y, 1.5);  // Newton: y1 = y0 (1.5 - 0.5 x y0^2)
+  rs = y * r;
+  sq = x * rs;
 }
 __device__ __forceinline__ double rcp_nr(double x) {
   const double y = __builtin_amdgcn_rcp(x);
   const double e = fma(-x, y, 1.0);
-  return fma(fma(e, e, e), y, y);     // two-term correction: ~2^-60
+  return fma(e, y, y);                // one Newton step: ~2^-46
 }
 // exp(x) for x < ~700 (the pair term has x <= 0, the obstacle term x <= radius/sigma):
 // no overflow handling; underflows to 0 through ldexp.
@@ -68,9 +65,9 @@ __device__ __forceinline__ double exp_fast(const poly_consts &pc, double x) {
   const double k = __builtin_rint(x * 1.4426950408889634074);
   double r = fma(k, -6.93147180369123816490e-01, x);
   r = fma(k, -1.90821492927058770002e-10, r);
-  double p = pc.ex[10];
+  double p = pc.ex[9];
 #pragma unroll
-  for (int n = 9; n >= 0; --n) p = fma(p, r, pc.ex[n]);
+  for (int n = 8; n >= 0; --n) p = fma(p, r, pc.ex[n]);
   return __builtin_amdgcn_ldexp(p, static_cast<int>(k));  // v_cvt_i32_f64 saturates, ldexp flushes to 0
 }
 // |atan2(y, x)| for y >= 0, result in [0, pi].  (y, x) != (0, 0).
@@ -79,9 +76,9 @@ __device__ __forceinline__ double atan2_abs(const poly_consts &pc, double y, dou
   const double mn = fmin(y, ax), mx = fmax(y, ax);
   const double q = mn * rcp_nr(fmax(mx, 1e-300));  // (0,0) -> 0, no NaN
   const double z = q * q;
-  double p = pc.at[16];
+  double p = pc.at[15];
 #pragma unroll
-  for (int n = 15; n >= 0; --n) p = fma(p, z, pc.at[n]);
+  for (int n = 14; n >= 0; --n) p = fma(p, z, pc.at[n]);
   double a = p * q;                                   // atan(q), q in [0,1]
   a = (y > ax) ? (1.57079632679489661923 - a) : a;    // octant fold
   a = (x < 0.0) ? (3.14159265358979323846 - a) : a;   // half-plane fold

@@ -24,14 +24,14 @@ def main():
         q = np.sqrt(np.maximum(z, 0.0))
         return np.where(q > 1e-8, np.arctan(q) / np.where(q > 0, q, 1.0), 1.0 - z / 3.0)
 
-    ca = fit(g, 0.0, 1.0, 16)
+    ca = fit(g, 0.0, 1.0, 15)
     q = np.linspace(0, 1, 400001)
     err = np.abs(q * horner(ca, q * q) - np.arctan(q))
     print("// atan(q) = q * P(q*q), q in [0,1]; max abs err %.2e (float64 Horner)" % err.max())
     print("constexpr double kAtanP[%d] = {" % len(ca))
     print(",\n".join("    %.17e" % v for v in ca) + "};")
     h = np.log(2.0) / 2
-    ce = fit(np.exp, -h * 1.0001, h * 1.0001, 10)
+    ce = fit(np.exp, -h * 1.0001, h * 1.0001, 9)
     r = np.linspace(-h, h, 400001)
     err = np.abs(horner(ce, r) / np.exp(r) - 1)
     print("// exp(r), |r| <= ln2/2; max rel err %.2e" % err.max())
