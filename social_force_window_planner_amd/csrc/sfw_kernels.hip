@@ -91,31 +91,30 @@ __device__ double footprint_cost(const sfw_launch &L, double x, double y, double
     if (code == 254 || code == 253) return -1.0;
     return static_cast<double>(code);
   }
+  // Every footprint vertex is the end of one edge and the start of the next, so
+  // its cell is computed once (the reference converts it twice, same result).
+  // Any vertex off the map makes the pose illegal (-3); which negative code wins
+  // when several apply does not matter to scoreTrajectory (all map to -1.0).
   double fc = 0.0;
-  // first vertex of edge 0
   double qx = L.footprint[0], qy = L.footprint[1];
-  double ax = x + (qx * c - qy * s), ay = y + (qx * s + qy * c);
-  const double fx0 = ax, fy0 = ay;
+  unsigned fx0, fy0;
+  if (!world_to_map(L, x + (qx * c - qy * s), y + (qx * s + qy * c), fx0, fy0)) return -3.0;
+  unsigned x0 = fx0, y0 = fy0;
   for (int e = 0; e < K; ++e) {
-    double bx, by;
-    double sx0 = ax, sy0 = ay;
+    unsigned x1, y1;
     if (e + 1 < K) {
       qx = L.footprint[2 * (e + 1)];
       qy = L.footprint[2 * (e + 1) + 1];
-      bx = x + (qx * c - qy * s);
-      by = y + (qx * s + qy * c);
+      if (!world_to_map(L, x + (qx * c - qy * s), y + (qx * s + qy * c), x1, y1)) return -3.0;
     } else {  // closing edge: back() -> front()
-      bx = fx0;
-      by = fy0;
+      x1 = fx0;
+      y1 = fy0;
     }
-    unsigned x0, y0, x1, y1;
-    if (!world_to_map(L, sx0, sy0, x0, y0)) return -3.0;
-    if (!world_to_map(L, bx, by, x1, y1)) return -3.0;
     const double lc = line_cost(L, (int)x0, (int)y0, (int)x1, (int)y1);
     fc = fmax(lc, fc);
     if (lc < 0) return lc;
-    ax = bx;
-    ay = by;
+    x0 = x1;
+    y0 = y1;
   }
   return fc;
 }

@@ -327,3 +327,29 @@ def test_multi_gpu_key_and_index_base(hip_mod):
     _, win = multi_gpu.lexicographic_min(keys)
     vx, vth, idx = multi_gpu.cmd_from_key(win, w.nw, scene.linvels, scene.angvels)
     assert (idx, vx, vth) == (best["index"], best["vx"], best["vtheta"])
+
+
+# ---------------------------------------------------------------------------
+# SFW_PRECISION_F32: forces in float, state / integration / thresholds in double.
+# Tolerance = the north-star bound (1e-4 relative); the selected command must
+# match unless the oracle's two best costs are closer than that bound.
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw", [
+    ("cfg2", {}),
+    ("target", dict(nv=48, nw=48)),
+    ("cfg3", dict(nv=24, nw=24)),
+    ("cfg5", dict(nv=12, nw=12)),
+    ("cfg2", dict(nv=40, nw=40, n_obstacles=32, seed=13)),
+    ("ref5x9", {}),
+])
+def test_f32_forces_mode_within_north_star_tolerance(oracle_mod, hip_mod, name, kw):
+    w = dataclasses.replace(syn.WORKLOADS[name], **kw)
+    scene, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w, n_threads=64, precision=SFW_PRECISION_F32)
+    assert np.array_equal(oc < 0, gc < 0)
+    v = oc >= 0
+    rel = np.abs(gc[v] - oc[v]) / np.abs(oc[v])
+    assert rel.max() <= RTOL_NORTH_STAR, f"max rel err {rel.max():.3e}"
+    assert np.median(rel) <= 1e-6
+    if gb["index"] != ob["index"]:  # only legal when the oracle itself cannot separate the two
+        assert abs(oc[gb["index"]] - ob["cost"]) <= RTOL_NORTH_STAR * ob["cost"]
+    assert gb["n_valid"] == ob["n_valid"]
