@@ -709,4 +709,132 @@ int64_t sfwo_planner_last_costs(void *p, double *out, int64_t cap) {
   if (out) std::memcpy(out, c.data(), sizeof(double) * (size_t)std::min(n, cap));
   return n;
 }
+
+// ---- sensor-interface restatement ------------------
+// ref: src/sensor_interface.cpp laserCb :103-294, peopleCb :418-528, odomCb
+// :534-581, getAgents :618-631.  One fixed 2-D transform stands in for tf.
+struct sfwo_si {
+  float max_robot_vel_x, robot_radius, person_radius, max_obstacle_dist, naive_goal_time, people_velocity;
+  double tx, ty, yaw;
+  bool tf_ok, running = false, odom_received = false;
+  std::vector<sfw_agent> agents;
+  std::vector<double> obstacles, agent_obstacles;
+  std::vector<double> people_xy;  // last people message, controller frame unknown -> raw + frame flag
+  bool people_in_ctrl = true;
+};
+void *sfwo_si_create(const float *p, double tx, double ty, double yaw, int32_t tf_ok) {
+  sfwo_si *h = new sfwo_si();
+  h->max_robot_vel_x = p[0]; h->robot_radius = p[1]; h->person_radius = p[2];
+  h->max_obstacle_dist = p[3]; h->naive_goal_time = p[4]; h->people_velocity = p[5];
+  h->tx = tx; h->ty = ty; h->yaw = yaw; h->tf_ok = tf_ok != 0;
+  sfw_agent r;
+  std::memset(&r, 0, sizeof(r));
+  r.desired_velocity = h->max_robot_vel_x;  // ref :33-37
+  r.radius = h->robot_radius;
+  r.group_id = -1;
+  h->agents.push_back(r);
+  return h;
+}
+void sfwo_si_destroy(void *hv) { delete static_cast<sfwo_si *>(hv); }
+void sfwo_si_start(void *hv) { static_cast<sfwo_si *>(hv)->running = true; }
+void sfwo_si_stop(void *hv) { static_cast<sfwo_si *>(hv)->running = false; }
+void sfwo_si_odom(void *hv, double x, double y, double yaw, double vx, double vy, double wz) {
+  sfwo_si *h = static_cast<sfwo_si *>(hv);
+  (void)yaw; (void)wz;
+  if (!h->running) return;
+  h->odom_received = true;
+  h->agents[0].x = x; h->agents[0].y = y;
+  h->agents[0].vx = vx; h->agents[0].vy = vy;  // local-frame twist, ref :565-575
+}
+void sfwo_si_people(void *hv, int32_t in_ctrl, const double *rows, const int32_t *ids, const int32_t *groups,
+                    int32_t n) {
+  sfwo_si *h = static_cast<sfwo_si *>(hv);
+  if (!h->running || !h->odom_received) return;
+  h->people_xy.clear();
+  for (int i = 0; i < n; ++i) { h->people_xy.push_back(rows[6 * i]); h->people_xy.push_back(rows[6 * i + 1]); }
+  h->people_in_ctrl = in_ctrl != 0;
+  if (!in_ctrl && !h->tf_ok) return;
+  const double c = std::cos(h->yaw), s = std::sin(h->yaw);
+  std::vector<sfw_agent> out;
+  for (int i = 0; i < n; ++i) {
+    const double *r = rows + 6 * i;
+    sfw_agent a;
+    std::memset(&a, 0, sizeof(a));
+    a.id = ids[i]; a.group_id = groups[i];
+    if (in_ctrl) { a.x = r[0]; a.y = r[1]; a.vx = r[3]; a.vy = r[4]; }
+    else {
+      a.x = h->tx + c * r[0] - s * r[1]; a.y = h->ty + s * r[0] + c * r[1];
+      a.vx = c * r[3] - s * r[4]; a.vy = s * r[3] + c * r[4];
+    }
+    a.radius = h->person_radius;
+    a.goal_x = a.x + h->naive_goal_time * a.vx;   // ref :498-501
+    a.goal_y = a.y + h->naive_goal_time * a.vy;
+    a.goal_radius = h->person_radius;
+    a.has_goal = 1;
+    a.desired_velocity = h->people_velocity;
+    out.push_back(a);
+  }
+  h->agents.resize((size_t)n + 1);
+  h->agent_obstacles = h->obstacles;              // ref :513-524
+  for (int i = 0; i < n; ++i) h->agents[(size_t)i + 1] = out[(size_t)i];
+}
+void sfwo_si_laser(void *hv, int32_t in_ctrl, float angle_min, float angle_inc, const float *ranges, int32_t n) {
+  sfwo_si *h = static_cast<sfwo_si *>(hv);
+  if (!h->running || !h->odom_received) return;
+  std::vector<double> pts;
+  float ang = angle_min;
+  for (int i = 0; i < n; ++i) {
+    const float r = ranges[i];
+    if (!std::isnan(r) && std::isfinite(r) && r < h->max_obstacle_dist) {
+      pts.push_back(r * std::cos(ang));  // float product, ref :125-126
+      pts.push_back(r * std::sin(ang));
+    }
+    ang += angle_inc;
+  }
+  if (pts.empty()) { h->obstacles.clear(); return; }
+  if (!in_ctrl && h->tf_ok) {
+    const double c = std::cos(h->yaw), s = std::sin(h->yaw);
+    for (size_t i = 0; i + 1 < pts.size(); i += 2) {
+      const double x = pts[i], y = pts[i + 1];
+      pts[i] = h->tx + c * x - s * y;
+      pts[i + 1] = h->ty + s * x + c * y;
+    }
+  }
+  std::vector<double> ppl = h->people_xy;
+  if (!ppl.empty() && !h->people_in_ctrl) {
+    if (!h->tf_ok) return;  // ref :195-202
+    const double c = std::cos(h->yaw), s = std::sin(h->yaw);
+    for (size_t i = 0; i + 1 < ppl.size(); i += 2) {
+      const double x = ppl[i], y = ppl[i + 1];
+      ppl[i] = h->tx + c * x - s * y;
+      ppl[i + 1] = h->ty + s * x + c * y;
+    }
+  }
+  if (!ppl.empty()) {  // ref :211-229
+    std::vector<double> kept;
+    for (size_t i = 0; i + 1 < pts.size(); i += 2) {
+      bool rm = false;
+      for (size_t j = 0; j + 1 < ppl.size() && !rm; j += 2) {
+        const float dx = (float)(pts[i] - ppl[j]), dy = (float)(pts[i + 1] - ppl[j + 1]);
+        rm = hypotf(dx, dy) <= h->person_radius;
+      }
+      if (!rm) { kept.push_back(pts[i]); kept.push_back(pts[i + 1]); }
+    }
+    pts.swap(kept);
+  }
+  h->obstacles = pts;
+}
+int32_t sfwo_si_get_agents(void *hv, sfw_agent *out, int32_t cap, double *obs_out, int32_t obs_cap, int32_t *O_out,
+                           double *laser_out, int32_t laser_cap, int32_t *L_out) {
+  sfwo_si *h = static_cast<sfwo_si *>(hv);
+  const int A = (int)h->agents.size();
+  for (int i = 0; i < A && i < cap; ++i) out[i] = h->agents[(size_t)i];
+  const int O = (int)(h->agent_obstacles.size() / 2);
+  for (int i = 0; i < 2 * O && i < 2 * obs_cap; ++i) obs_out[i] = h->agent_obstacles[(size_t)i];
+  *O_out = O;
+  const int Ln = (int)(h->obstacles.size() / 2);
+  for (int i = 0; i < 2 * Ln && i < 2 * laser_cap; ++i) laser_out[i] = h->obstacles[(size_t)i];
+  *L_out = Ln;
+  return A;
+}
 }  // extern "C"

@@ -177,3 +177,93 @@ int sfwh_trajectory_points(void *hv, int64_t index, double *xyth, int32_t cap) {
 }
 double sfwh_get_yaw(double x, double y, double z, double w) { return getYaw(Quaternion{x, y, z, w}); }
 }
+
+// ---------------------------------------------------------------------------
+// SFMSensorInterface shim.  One fixed transform stands in
+// for tf: every frame other than "odom" maps to the controller frame through it.
+// ---------------------------------------------------------------------------
+#include "sensor_interface.hpp"
+
+namespace {
+struct SiHandle {
+  Transform2D tf;
+  bool tf_ok = true;
+  std::unique_ptr<SFMSensorInterface> si;
+};
+}  // namespace
+
+extern "C" {
+
+// p = {max_robot_vel_x, robot_radius, person_radius, max_obstacle_dist, naive_goal_time, people_velocity}
+void *sfwh_si_create(const float *p, double tx, double ty, double yaw, int32_t tf_ok) {
+  SiHandle *h = new SiHandle();
+  h->tf = Transform2D{tx, ty, yaw};
+  h->tf_ok = tf_ok != 0;
+  InterfaceParams ip;
+  ip.max_robot_vel_x_ = p[0]; ip.robot_radius_ = p[1]; ip.person_radius_ = p[2];
+  ip.max_obstacle_dist_ = p[3]; ip.naive_goal_time_ = p[4]; ip.people_velocity_ = p[5];
+  SiHandle *raw = h;
+  h->si.reset(new SFMSensorInterface(ip, [raw](const std::string &, const std::string &, Transform2D &out) {
+    out = raw->tf;
+    return raw->tf_ok;
+  }));
+  return h;
+}
+void sfwh_si_destroy(void *hv) { delete static_cast<SiHandle *>(hv); }
+void sfwh_si_start(void *hv) { static_cast<SiHandle *>(hv)->si->start(); }
+void sfwh_si_stop(void *hv) { static_cast<SiHandle *>(hv)->si->stop(); }
+void sfwh_si_odom(void *hv, double x, double y, double yaw, double vx, double vy, double wz) {
+  Odometry o;
+  o.frame_id = "odom";
+  o.pose.position.x = x;
+  o.pose.position.y = y;
+  o.pose.orientation = quaternionFromYaw(yaw);
+  o.twist.linear.x = vx;
+  o.twist.linear.y = vy;
+  o.twist.angular.z = wz;
+  static_cast<SiHandle *>(hv)->si->odomCb(o);
+}
+// rows: n x {x, y, yaw, vx, vy, wz}; ids/groups: n
+void sfwh_si_people(void *hv, int32_t in_controller_frame, const double *rows, const int32_t *ids,
+                    const int32_t *groups, int32_t n) {
+  People pp;
+  pp.frame_id = in_controller_frame ? "odom" : "map";
+  for (int i = 0; i < n; ++i) {
+    Person p;
+    p.position.x = rows[6 * i];
+    p.position.y = rows[6 * i + 1];
+    p.position.z = rows[6 * i + 2];
+    p.velocity.x = rows[6 * i + 3];
+    p.velocity.y = rows[6 * i + 4];
+    p.velocity.z = rows[6 * i + 5];
+    p.tags = {std::to_string(ids[i]), std::to_string(groups[i])};
+    pp.people.push_back(p);
+  }
+  static_cast<SiHandle *>(hv)->si->peopleCb(pp);
+}
+void sfwh_si_laser(void *hv, int32_t in_controller_frame, float angle_min, float angle_inc, const float *ranges,
+                   int32_t n) {
+  LaserScan s;
+  s.frame_id = in_controller_frame ? "odom" : "base_laser";
+  s.angle_min = angle_min;
+  s.angle_increment = angle_inc;
+  s.ranges.assign(ranges, ranges + n);
+  static_cast<SiHandle *>(hv)->si->laserCb(s);
+}
+// returns A; *O_out = number of obstacle points the agents carry; *L_out = points of the last scan
+int32_t sfwh_si_get_agents(void *hv, sfw_agent *out, int32_t cap, double *obs_out, int32_t obs_cap, int32_t *O_out,
+                           double *laser_out, int32_t laser_cap, int32_t *L_out) {
+  SiHandle *h = static_cast<SiHandle *>(hv);
+  const AgentSet s = h->si->getAgents();
+  const int A = static_cast<int>(s.agents.size());
+  for (int i = 0; i < A && i < cap; ++i) out[i] = s.agents[i];
+  const int O = static_cast<int>(s.obstacles_xy.size() / 2);
+  for (int i = 0; i < 2 * O && i < 2 * obs_cap; ++i) obs_out[i] = s.obstacles_xy[i];
+  *O_out = O;
+  const std::vector<double> &l = h->si->obstacles();
+  const int Ln = static_cast<int>(l.size() / 2);
+  for (int i = 0; i < 2 * Ln && i < 2 * laser_cap; ++i) laser_out[i] = l[i];
+  *L_out = Ln;
+  return A;
+}
+}

@@ -1,0 +1,95 @@
+"""Error conventions of the C ABI on a real device (include/sfw_hip.h): status
+codes, last_error text, invalid trajectory = data (-1.0), call-order checks."""
+import ctypes as C
+import dataclasses
+
+import numpy as np
+import pytest
+
+from social_force_window_planner_amd import synthetic as syn
+from social_force_window_planner_amd._abi import (SFW_ERR_INVALID_ARG, SFW_ERR_STATE, SFW_ERR_UNSUPPORTED, SFW_OK,
+                                                   SfwAgent, SfwBest, SfwGoalArgs, SfwRobotState, default_params)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_call_order_and_argument_errors(hip_mod):
+    L = hip_mod.lib()
+    g = hip_mod.HipScorer(default_params())
+    scene = syn.make_scene("ref5x9")
+    rs, ga = SfwRobotState(*scene.robot_state), SfwGoalArgs(*scene.goal_args)
+    lin, ang = scene.linvels, scene.angvels
+    costs = np.zeros(45)
+    best = SfwBest()
+    # scoring before a costmap was set
+    rc = L.sfw_score_grid(g._h, C.byref(rs), lin.ctypes.data, 5, ang.ctypes.data, 9, C.byref(ga), costs.ctypes.data,
+                          C.byref(best))
+    assert rc == SFW_ERR_STATE and b"costmap" in L.sfw_last_error(g._h)
+    assert L.sfw_grid_launch(g._h) == SFW_ERR_STATE
+    assert L.sfw_grid_fetch(g._h, None, C.byref(best), None) == SFW_ERR_STATE
+    g.load_scene(scene)
+    assert L.sfw_score_grid(g._h, C.byref(rs), lin.ctypes.data, 0, ang.ctypes.data, 9, C.byref(ga), None, None) == SFW_ERR_INVALID_ARG
+    assert L.sfw_score_grid(g._h, None, lin.ctypes.data, 5, ang.ctypes.data, 9, C.byref(ga), None, None) == SFW_ERR_INVALID_ARG
+    assert L.sfw_set_costmap(g._h, None, 10, 10, 0.0, 0.0, 0.05) == SFW_ERR_INVALID_ARG
+    assert L.sfw_set_costmap(g._h, scene.cells.ctypes.data, 10, 10, 0.0, 0.0, 0.0) == SFW_ERR_INVALID_ARG
+    assert L.sfw_set_footprint(g._h, None, 3) == SFW_ERR_INVALID_ARG
+    # outputs are optional
+    assert L.sfw_score_grid(g._h, C.byref(rs), lin.ctypes.data, 5, ang.ctypes.data, 9, C.byref(ga), None, None) == SFW_OK
+    # group forces are not built: refused, previous agent set stays in place
+    grouped = (SfwAgent * 2)(scene.agents[0], scene.agents[1])
+    grouped[1].group_id = 4
+    assert L.sfw_set_agents(g._h, C.addressof(grouped), 2, None, 0) == SFW_ERR_UNSUPPORTED
+    c1, b1 = g.score_grid(scene.robot_state, lin, ang, scene.goal_args)
+    g2 = hip_mod.HipScorer(default_params())
+    g2.load_scene(scene)
+    c2, b2 = g2.score_grid(scene.robot_state, lin, ang, scene.goal_args)
+    assert np.array_equal(c1, c2) and b1 == b2
+
+
+def test_zero_agents_and_reuse_of_a_handle(oracle_mod, hip_mod):
+    """A = 0 (no agent vector at all): social work is 0; then the same handle is
+    reused with a different costmap size, agent count and grid size."""
+    scene = syn.make_scene("cfg1")
+    p = default_params(sim_time=0.5)
+    g = hip_mod.HipScorer(p)
+    o = oracle_mod.OracleScorer(default_params(sim_time=0.5))
+    for s in (g, o):
+        s.set_costmap(scene.cells, scene.origin_x, scene.origin_y, scene.resolution)
+        s.set_footprint(scene.footprint)
+        s.set_agents((SfwAgent * 0)())
+    gc, gb = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    oc, ob = o.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert np.allclose(gc, oc, rtol=1e-13, atol=0) and gb["index"] == ob["index"]
+    for name in ("ref5x9", "cfg2"):
+        w = dataclasses.replace(syn.WORKLOADS[name], nv=min(syn.WORKLOADS[name].nv, 16), nw=9 if name == "ref5x9" else 16)
+        if name == "ref5x9":
+            w = syn.WORKLOADS[name]
+        sc = syn.make_scene(w)
+        pp = default_params(sim_time=w.sim_time, sim_granularity=w.sim_granularity)
+        g.set_params(pp)
+        o.set_params(default_params(sim_time=w.sim_time, sim_granularity=w.sim_granularity))
+        g.load_scene(sc)
+        o.load_scene(sc)
+        gc, gb = g.score_grid(sc.robot_state, sc.linvels, sc.angvels, sc.goal_args)
+        oc, ob = o.score_grid(sc.robot_state, sc.linvels, sc.angvels, sc.goal_args)
+        v = oc >= 0
+        assert np.array_equal(oc < 0, gc < 0) and np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= 1e-9
+        assert gb["index"] == ob["index"]
+
+
+def test_many_agents_use_the_flat_kernel(oracle_mod, hip_mod):
+    """A = 300 > 128 agents: the LDS-resident flat kernel; a few samples only."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg4"], nv=2, nw=3, n_people=299, seed=9)
+    scene = syn.make_scene(w)
+    p = default_params()
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    o = oracle_mod.OracleScorer(default_params())
+    o.load_scene(scene)
+    gc, gb = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    oc, ob = o.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args, n_threads=6)
+    assert np.array_equal(oc < 0, gc < 0)
+    v = oc >= 0
+    if v.any():
+        assert np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= 1e-9
+    assert gb["index"] == ob["index"]
