@@ -42,7 +42,7 @@ typedef enum sfw_status {
   SFW_ERR_NO_DEVICE = -2,    /* no HIP device / kernels cannot be launched  */
   SFW_ERR_HIP = -3,          /* a HIP runtime call failed (see last_error)  */
   SFW_ERR_STATE = -4,        /* call order violated (e.g. no costmap set)   */
-  SFW_ERR_UNSUPPORTED = -5   /* e.g. group forces (groupId >= 0), see below */
+  SFW_ERR_UNSUPPORTED = -5   /* input does not fit the device (e.g. LDS)     */
 } sfw_status;
 
 /* Cost sentinels written into the per-sample cost vector. */
@@ -52,9 +52,9 @@ typedef enum sfw_status {
 
 /* Arithmetic mode of the social-force kernel. */
 #define SFW_PRECISION_F64 0 /* parity mode: everything in double            */
-#define SFW_PRECISION_F32 1 /* fast mode: robot rollout + costmap in double,
-                               pedestrian dynamics in float (documented
-                               threshold-flip risk)           */
+#define SFW_PRECISION_F32 1 /* fast mode: agent state, integration and every
+                               threshold stay double; only the pair/obstacle
+                               FORCES are evaluated in float  */
 
 /*
  * Scoring parameters = the subset of ControllerParams
@@ -84,6 +84,9 @@ typedef struct sfw_params {
   double sfm_n;                     /* 2.0  */
   double sfm_n_prime;               /* 3.0  */
   double sfm_relaxation_time;       /* 0.5  */
+  double sfm_force_factor_group_gaze;      /* 3.0 */
+  double sfm_force_factor_group_coherence; /* 2.0 */
+  double sfm_force_factor_group_repulsion; /* 1.0 */
   int32_t precision;                /* SFW_PRECISION_*                      */
   int32_t reserved1;
 } sfw_params;
@@ -105,8 +108,9 @@ typedef struct sfw_agent {
   int32_t has_goal;        /* goals non-empty (people: 1, robot at t0: 0)   */
   int32_t id;              /* Agent::id — the robot-on-person force skips a
                               person whose id equals the robot's            */
-  int32_t group_id;        /* Agent::groupId; must be < 0 (group forces are
-                              not built yet -> SFW_ERR_UNSUPPORTED)         */
+  int32_t group_id;        /* Agent::groupId (people_msgs tags[1]); < 0 = no
+                              group.  Members of a group of >= 2 agents feel
+                              lightsfm's gaze/coherence/repulsion forces    */
   int32_t reserved;
 } sfw_agent;
 

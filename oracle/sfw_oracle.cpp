@@ -30,6 +30,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -230,18 +231,64 @@ static inline V2 sfm_pair(const sfw_params &p, const Agent &me, const Agent &oth
   double fa = -(double)angle_sign(theta) * std::exp(-norm(diff) / B - sq_a * sq_a);
   return p.sfm_force_factor_social * (fv * interDir + fa * left_normal(interDir));
 }
+// lightsfm Group: member indices and their mean position.
+struct Group {
+  std::vector<size_t> members;
+  V2 center;
+};
+// lightsfm computeGroupForce (non-_PAPER_VERSION_ branch; SURVEY.md Appendix A, UNPINNED):
+//   gaze: if the centre of mass of the OTHER members is more than 90 deg off the
+//         desired direction, pull along the desired direction;
+//   coherence: relCOM * k_c * (tanh(|relCOM| - (n-1)/2) + 1) / 2;
+//   repulsion: sum of (p_a - p_b) over overlapping members.
+static V2 sfm_group(const sfw_params &p, size_t index, V2 desiredDir, const std::vector<Agent> &ag,
+                    const std::map<int, Group> &groups) {
+  const Agent &a = ag[index];
+  auto it = groups.find(a.groupId);
+  if (it == groups.end() || it->second.members.size() < 2) return {0, 0};
+  const Group &g = it->second;
+  const double n = (double)g.members.size();
+  V2 gaze{0, 0};
+  V2 com = (1.0 / (n - 1.0)) * (n * g.center - a.position);
+  V2 rel = com - a.position;
+  const double ep = desiredDir.x * rel.x + desiredDir.y * rel.y;
+  const double comAngle = wrap_angle(std::acos(ep / (norm(desiredDir) * norm(rel))));
+  if (comAngle > wrap_angle(90.0 * M_PI / 180.0)) {  // NaN (no desired direction) compares false
+    const double dd2 = desiredDir.x * desiredDir.x + desiredDir.y * desiredDir.y;
+    gaze = p.sfm_force_factor_group_gaze * ((ep / dd2) * desiredDir);
+  }
+  rel = g.center - a.position;
+  const double dist = norm(rel), maxd = (n - 1.0) / 2.0;
+  V2 coh = rel * (p.sfm_force_factor_group_coherence * (std::tanh(dist - maxd) + 1.0) / 2.0);
+  V2 rep{0, 0};
+  for (size_t m : g.members) {
+    if (m == index) continue;
+    V2 d = a.position - ag[m].position;
+    if (norm(d) < a.radius + ag[m].radius) rep = rep + d;
+  }
+  rep = rep * p.sfm_force_factor_group_repulsion;
+  return gaze + coh + rep;
+}
 // sfm::SFM.computeForces(std::vector<Agent>&)   (call site src/sfw_planner.cpp:592)
 static void sfm_compute_forces(const sfw_params &p, std::vector<Agent> &ag) {
+  std::map<int, Group> groups;
   for (size_t i = 0; i < ag.size(); ++i) {
-    sfm_desired(p, ag[i]);
+    if (ag[i].groupId < 0) continue;
+    Group &g = groups[ag[i].groupId];
+    g.members.push_back(i);
+    g.center = g.center + ag[i].position;
+  }
+  for (auto &kv : groups) kv.second.center = kv.second.center / (double)kv.second.members.size();
+  for (size_t i = 0; i < ag.size(); ++i) {
+    const V2 dir = sfm_desired(p, ag[i]);
     sfm_obstacle(p, ag[i]);
     ag[i].socialForce = {0, 0};
     for (size_t j = 0; j < ag.size(); ++j) {
       if (j == i) continue;
       ag[i].socialForce = ag[i].socialForce + sfm_pair(p, ag[i], ag[j]);
     }
-    // groupForce == 0: every agent has groupId < 0 (enforced at set_agents)
-    ag[i].globalForce = ag[i].desiredForce + ag[i].socialForce + ag[i].obstacleForce;
+    const V2 grp = groups.empty() ? V2{0, 0} : sfm_group(p, i, dir, ag, groups);
+    ag[i].globalForce = ag[i].desiredForce + ag[i].socialForce + ag[i].obstacleForce + grp;
   }
 }
 // sfm::SFM.computeForces(Agent& me, std::vector<Agent>&)  (call site :697);
@@ -560,8 +607,6 @@ int sfwo_set_footprint(void *h, const double *xy, int32_t K) {
 int sfwo_set_agents(void *h, const sfw_agent *a, int32_t A, const double *obs, int32_t O) {
   if (!h || A < 0 || O < 0 || (A > 0 && !a) || (O > 0 && !obs)) return SFW_ERR_INVALID_ARG;
   World *w = static_cast<World *>(h);
-  for (int i = 0; i < A; ++i)
-    if (a[i].group_id >= 0) return SFW_ERR_UNSUPPORTED;
   w->obstacles.clear();
   for (int i = 0; i < O; ++i) w->obstacles.push_back({obs[2 * i], obs[2 * i + 1]});
   w->agents.clear();
@@ -651,6 +696,28 @@ int sfwo_pair_force(const sfw_params *p, const sfw_agent *me, const sfw_agent *o
   a.position = {me->x, me->y}; a.velocity = {me->vx, me->vy};
   b.position = {other->x, other->y}; b.velocity = {other->vx, other->vy};
   sfwo::V2 f = sfwo::sfm_pair(*p, a, b);
+  fxy[0] = f.x; fxy[1] = f.y;
+  return SFW_OK;
+}
+// Group force on agent `index` of a small agent set (positions/goals/groups), for KATs.
+int sfwo_group_force(const sfw_params *p, const sfw_agent *a, int32_t A, int32_t index, double *fxy) {
+  std::vector<sfwo::Agent> ag((size_t)A);
+  std::map<int, sfwo::Group> groups;
+  for (int i = 0; i < A; ++i) {
+    ag[(size_t)i].position = {a[i].x, a[i].y};
+    ag[(size_t)i].velocity = {a[i].vx, a[i].vy};
+    ag[(size_t)i].radius = a[i].radius;
+    ag[(size_t)i].desiredVelocity = a[i].desired_velocity;
+    ag[(size_t)i].groupId = a[i].group_id;
+    if (a[i].has_goal) ag[(size_t)i].goals.push_back({{a[i].goal_x, a[i].goal_y}, a[i].goal_radius});
+    if (a[i].group_id >= 0) {
+      groups[a[i].group_id].members.push_back((size_t)i);
+      groups[a[i].group_id].center = groups[a[i].group_id].center + ag[(size_t)i].position;
+    }
+  }
+  for (auto &kv : groups) kv.second.center = kv.second.center / (double)kv.second.members.size();
+  const sfwo::V2 dir = sfwo::sfm_desired(*p, ag[(size_t)index]);
+  const sfwo::V2 f = sfwo::sfm_group(*p, (size_t)index, dir, ag, groups);
   fxy[0] = f.x; fxy[1] = f.y;
   return SFW_OK;
 }

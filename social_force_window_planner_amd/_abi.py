@@ -41,6 +41,9 @@ class SfwParams(C.Structure):
         ("sfm_n", C.c_double),
         ("sfm_n_prime", C.c_double),
         ("sfm_relaxation_time", C.c_double),
+        ("sfm_force_factor_group_gaze", C.c_double),
+        ("sfm_force_factor_group_coherence", C.c_double),
+        ("sfm_force_factor_group_repulsion", C.c_double),
         ("precision", C.c_int32),
         ("reserved1", C.c_int32),
     ]
@@ -69,6 +72,9 @@ def default_params(**overrides):
     p.sfm_n = 2.0
     p.sfm_n_prime = 3.0
     p.sfm_relaxation_time = 0.5
+    p.sfm_force_factor_group_gaze = 3.0
+    p.sfm_force_factor_group_coherence = 2.0
+    p.sfm_force_factor_group_repulsion = 1.0
     p.precision = SFW_PRECISION_F64
     for k, v in overrides.items():
         if not hasattr(p, k):

@@ -55,7 +55,8 @@ struct sfw_planner_s {
   int K = 0;
   dev_buf<double> agent_pos, agent_vel, obstacles;
   dev_buf<sfw_agent_const> agent_c;
-  int A = 0, O = 0;
+  dev_buf<int32_t> agent_grp, grp_off, grp_mem;
+  int A = 0, O = 0, NG = 0, n_grp_mem = 0;
 
   // staged grid
   dev_buf<double> linvels, angvels;
@@ -141,6 +142,11 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.A = h->A;
   L.obstacles = h->obstacles.p;
   L.O = h->O;
+  L.agent_grp = h->agent_grp.p;
+  L.grp_off = h->grp_off.p;
+  L.grp_mem = h->grp_mem.p;
+  L.NG = h->NG;
+  L.n_grp_mem = h->n_grp_mem;
   L.status = h->status.p;
   L.base_cost = h->base_cost.p;
   L.costs = h->costs.p;
@@ -204,7 +210,7 @@ int launch_common(sfw_handle h) {
   int64_t chunk = static_cast<int64_t>(std::min(h->rstep.cap, std::min(h->frame.cap, h->fcode.cap)) / S);
   if (chunk > T) chunk = T;
   if (chunk < 1) return fail(h, SFW_ERR_STATE, "robot-step table too small (params changed after stage?)");
-  const size_t lds = sfw_social_lds_bytes(h->A, h->O, h->params.precision);
+  const size_t lds = sfw_social_lds_bytes(h->A, h->O, h->NG, h->n_grp_mem);
   if (h->A > 0 && lds > 160 * 1024)
     return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
   SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
@@ -279,6 +285,9 @@ void sfw_params_default(sfw_params *p) {
   p->sfm_n = 2.0;
   p->sfm_n_prime = 3.0;
   p->sfm_relaxation_time = 0.5;
+  p->sfm_force_factor_group_gaze = 3.0;
+  p->sfm_force_factor_group_coherence = 2.0;
+  p->sfm_force_factor_group_repulsion = 1.0;
   p->precision = SFW_PRECISION_F64;
 }
 
@@ -320,6 +329,9 @@ int sfw_destroy(sfw_handle h) {
   h->agent_vel.release();
   h->obstacles.release();
   h->agent_c.release();
+  h->agent_grp.release();
+  h->grp_off.release();
+  h->grp_mem.release();
   h->linvels.release();
   h->angvels.release();
   h->status.release();
@@ -386,9 +398,6 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   if (!h) return SFW_ERR_INVALID_ARG;
   if (A < 0 || O < 0 || (A > 0 && !agents) || (O > 0 && !obstacles_xy))
     return fail(h, SFW_ERR_INVALID_ARG, "set_agents: bad arguments");
-  for (int i = 0; i < A; ++i)
-    if (agents[i].group_id >= 0)
-      return fail(h, SFW_ERR_UNSUPPORTED, "set_agents: group forces (group_id >= 0) are not built yet");
   SFW_HIP(h, hipSetDevice(h->device));
   SFW_HIP(h, hipStreamSynchronize(h->stream));
   std::vector<double> pos(2 * static_cast<size_t>(A > 0 ? A : 1)), vel(pos.size());
@@ -407,6 +416,30 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
     c.id = agents[i].id;
     c.has_goal = agents[i].has_goal ? 1 : 0;
   }
+  // groups: dense index in order of first appearance, CSR member lists in agent order
+  std::vector<int32_t> grp(static_cast<size_t>(A > 0 ? A : 1), -1), ids, off(1, 0), mem;
+  for (int i = 0; i < A; ++i) {
+    if (agents[i].group_id < 0) continue;
+    size_t q = 0;
+    while (q < ids.size() && ids[q] != agents[i].group_id) ++q;
+    if (q == ids.size()) ids.push_back(agents[i].group_id);
+    grp[i] = static_cast<int32_t>(q);
+  }
+  for (size_t q = 0; q < ids.size(); ++q) {
+    for (int i = 0; i < A; ++i)
+      if (grp[i] == static_cast<int32_t>(q)) mem.push_back(i);
+    off.push_back(static_cast<int32_t>(mem.size()));
+  }
+  if (mem.empty()) mem.push_back(0);
+  SFW_HIP(h, h->agent_grp.reserve(grp.size()));
+  SFW_HIP(h, h->grp_off.reserve(off.size()));
+  SFW_HIP(h, h->grp_mem.reserve(mem.size()));
+  SFW_HIP(h, hipMemcpyAsync(h->agent_grp.p, grp.data(), sizeof(int32_t) * grp.size(), hipMemcpyHostToDevice, h->stream));
+  SFW_HIP(h, hipMemcpyAsync(h->grp_off.p, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice, h->stream));
+  SFW_HIP(h, hipMemcpyAsync(h->grp_mem.p, mem.data(), sizeof(int32_t) * mem.size(), hipMemcpyHostToDevice, h->stream));
+  SFW_HIP(h, hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
+  h->NG = static_cast<int>(ids.size());
+  h->n_grp_mem = off.back();
   SFW_HIP(h, h->agent_pos.reserve(pos.size()));
   SFW_HIP(h, h->agent_vel.reserve(vel.size()));
   SFW_HIP(h, h->agent_c.reserve(cst.size()));

@@ -61,6 +61,12 @@ struct sfw_launch {
   int32_t A;
   const double *obstacles;         // O x (x,y)
   int32_t O;
+  // groups of >= 1 agents with group_id >= 0 (dense index q, CSR member lists)
+  const int32_t *agent_grp;        // A : dense group index or -1
+  const int32_t *grp_off;          // NG + 1
+  const int32_t *grp_mem;          // grp_off[NG] member agent indices, ascending per group
+  int32_t NG;
+  int32_t n_grp_mem;
   // per-sample outputs, indexed by GLOBAL sample index
   int32_t *status;       // T
   double *base_cost;     // T : vel + distance + angle + costmap terms (ref :663-666)
@@ -95,6 +101,6 @@ hipError_t sfw_launch_argmin(const double *costs, const double *linvels, const d
                              sfw_sel *out, hipStream_t stream);
 // Samples handled by one wave of the social kernel for A agents.
 int sfw_samples_per_wave(int A);
-size_t sfw_social_lds_bytes(int A, int O, int precision);
+size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem);
 
 #endif  // SFW_DEVICE_H_

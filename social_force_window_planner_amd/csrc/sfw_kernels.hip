@@ -249,6 +249,7 @@ template <typename R> struct sfm_consts {
   R lambda, gamma, neg_inv_gamma, n2, n_prime2, f_social;
   R f_obstacle, inv_sigma;
   double f_desired, inv_tau, dt, rr;
+  double f_gaze, f_coherence, f_repulsion;
 };
 
 // Force exerted ON agent i BY agent j (one term of lightsfm's
@@ -344,10 +345,10 @@ __device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const dou
 }
 
 struct lds_layout {
-  double2 *pos, *vel, *frc, *frj, *goal, *obs;
+  double2 *pos, *vel, *frc, *frj, *goal, *obs, *gcen;
   double *gr, *dv, *rad, *swp;
-  int *id, *hasgoal, *dead;
-  __device__ lds_layout(char *base, int A, int GA, int G, int O) {
+  int *id, *hasgoal, *dead, *grp, *goff, *gmem;
+  __device__ lds_layout(char *base, int A, int GA, int G, int O, int NG, int NM) {
     auto take = [&](size_t bytes) {
       char *p = base;
       base += (bytes + 15) & ~size_t(15);
@@ -366,8 +367,65 @@ struct lds_layout {
     id = reinterpret_cast<int *>(take(sizeof(int) * A));
     hasgoal = reinterpret_cast<int *>(take(sizeof(int) * GA));
     dead = reinterpret_cast<int *>(take(sizeof(int) * G));
+    gcen = reinterpret_cast<double2 *>(take(sizeof(double2) * (NG > 0 ? G * NG : 1)));
+    grp = reinterpret_cast<int *>(take(sizeof(int) * (NG > 0 ? A : 1)));
+    goff = reinterpret_cast<int *>(take(sizeof(int) * (NG + 1)));
+    gmem = reinterpret_cast<int *>(take(sizeof(int) * (NM > 0 ? NM : 1)));
   }
 };
+
+// lightsfm computeGroupForce (non-_PAPER_VERSION_ branch)
+// for agent i of sample g at position (px,py): gaze + coherence + repulsion.
+// Group centres (sums of member positions) must already be in s.gcen.  Rare
+// path: plain IEEE sqrt/div/acos/tanh, in double in both precision modes.
+template <typename R>
+__device__ double2 group_force(const sfm_consts<R> &k, const lds_layout &s, int NG, int g, int A, int i, int sl,
+                               double px, double py) {
+  const int q = s.grp[i];
+  if (q < 0) return double2{0.0, 0.0};
+  const int m0 = s.goff[q], m1 = s.goff[q + 1];
+  const double n = static_cast<double>(m1 - m0);
+  if (m1 - m0 < 2) return double2{0.0, 0.0};
+  const double2 csum = s.gcen[g * NG + q];
+  const double cx = csum.x / n, cy = csum.y / n;
+  // desired direction at this state (zero when the agent has no goal to walk to)
+  const double2 gl = s.goal[i];
+  const double ex = gl.x - px, ey = gl.y - py;
+  const double en = sqrt(ex * ex + ey * ey);
+  double ddx = 0.0, ddy = 0.0;
+  if (s.hasgoal[sl] && en > s.gr[i] && en > 0.0) { ddx = ex / en; ddy = ey / en; }
+  double fx = 0.0, fy = 0.0;
+  {  // gaze
+    const double w = 1.0 / (n - 1.0);
+    const double rx = w * (n * cx - px) - px, ry = w * (n * cy - py) - py;
+    const double ep = ddx * rx + ddy * ry;
+    const double ang = acos(ep / (sqrt(ddx * ddx + ddy * ddy) * sqrt(rx * rx + ry * ry)));
+    if (ang > 90.0 * M_PI / 180.0) {  // NaN (no desired direction) compares false
+      const double sc = k.f_gaze * (ep / (ddx * ddx + ddy * ddy));
+      fx = sc * ddx;
+      fy = sc * ddy;
+    }
+  }
+  {  // coherence
+    const double rx = cx - px, ry = cy - py;
+    const double dist = sqrt(rx * rx + ry * ry);
+    const double soft = k.f_coherence * (tanh(dist - (n - 1.0) / 2.0) + 1.0) / 2.0;
+    fx += rx * soft;
+    fy += ry * soft;
+  }
+  double rx = 0.0, ry = 0.0;  // repulsion between overlapping members
+  const double ra = s.rad[i];
+  for (int m = m0; m < m1; ++m) {
+    const int b = s.gmem[m];
+    if (b == i) continue;
+    const double2 pb = s.pos[g * A + b];
+    const double dx = px - pb.x, dy = py - pb.y;
+    if (sqrt(dx * dx + dy * dy) < ra + s.rad[b]) { rx += dx; ry += dy; }
+  }
+  fx += rx * k.f_repulsion;
+  fy += ry * k.f_repulsion;
+  return double2{fx, fy};
+}
 
 template <typename R> __device__ __forceinline__ sfm_consts<R> make_consts(const sfw_launch &L) {
   sfm_consts<R> k;
@@ -383,6 +441,9 @@ template <typename R> __device__ __forceinline__ sfm_consts<R> make_consts(const
   k.inv_tau = 1.0 / L.p.sfm_relaxation_time;
   k.dt = L.dt;
   k.rr = static_cast<double>(L.p.robot_radius * L.p.robot_radius);  // float product, ref :617
+  k.f_gaze = L.p.sfm_force_factor_group_gaze;
+  k.f_coherence = L.p.sfm_force_factor_group_coherence;
+  k.f_repulsion = L.p.sfm_force_factor_group_repulsion;
   return k;
 }
 
@@ -455,6 +516,7 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_l
 
 // Stage the per-launch constants and the initial agent state into LDS; returns
 // false when every sample of this wave was already rejected by K1.
+template <bool GROUPS>
 __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout &s, int lane, int G, int Gn,
                                            int64_t first_local) {
   const int A = L.A, O = L.O;
@@ -467,6 +529,11 @@ __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout
     s.id[i] = c.id;
   }
   for (int o = lane; o < O; o += WAVE) s.obs[o] = double2{L.obstacles[2 * o], L.obstacles[2 * o + 1]};
+  if constexpr (GROUPS) {
+    for (int i = lane; i < A; i += WAVE) s.grp[i] = L.agent_grp[i];
+    for (int q = lane; q <= L.NG; q += WAVE) s.goff[q] = L.grp_off[q];
+    for (int m = lane; m < L.n_grp_mem; m += WAVE) s.gmem[m] = L.grp_mem[m];
+  }
   if (lane < G) {
     int dead = 1;
     if (lane < Gn) dead = (L.status[L.chunk_begin + first_local + lane] != SFW_ST_VALID);
@@ -516,19 +583,20 @@ __device__ __forceinline__ void finish_wave(const sfw_launch &L, const lds_layou
 // the i-side force accumulates in registers, the j-side goes through one LDS
 // atomic whose addresses are all distinct within the instruction.
 // ---------------------------------------------------------------------------
-template <typename R, int NS>
-__global__ void __launch_bounds__(WAVE) sfw_social_kernel(const sfw_launch L, const int G) {
+template <typename R, int NS, bool GROUPS>
+__global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social_kernel(const sfw_launch L, const int G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int A = L.A, O = L.O, S = L.S;
   const int GA = G * A;
-  const lds_layout s(smem, A, GA, G, O);
+  const int NG = GROUPS ? L.NG : 0;  // GROUPS=false instantiation: no group code, lean register budget
+  const lds_layout s(smem, A, GA, G, O, NG, GROUPS ? L.n_grp_mem : 0);
   const int64_t first_local = static_cast<int64_t>(blockIdx.x) * G;
   const int64_t remain = L.chunk_count - first_local;
   const int Gn = remain < G ? static_cast<int>(remain) : G;
   const sfm_consts<R> k = make_consts<R>(L);
   const double inv_O = O > 0 ? 1.0 / O : 0.0;
-  if (!stage_wave(L, s, lane, G, Gn, first_local)) return;
+  if (!stage_wave<GROUPS>(L, s, lane, G, Gn, first_local)) return;
 
   // ---- this lane's slots --------------------------------------------------
   int sl_[NS], g_[NS], i_[NS];
@@ -567,6 +635,27 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel(const sfw_launch L, co
     }
   }
   __syncthreads();
+  // Group forces belong to the force at the CURRENT state, so they are added to
+  // the starting force after every state update (and once here for step 0).
+  auto add_group_forces = [&]() {
+    for (int q = lane; q < G * NG; q += WAVE) s.gcen[q] = double2{0.0, 0.0};
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NS; ++r)
+      if (ok_[r] && s.grp[i_[r]] >= 0) {
+        atomicAdd(&s.gcen[g_[r] * NG + s.grp[i_[r]]].x, px[r]);
+        atomicAdd(&s.gcen[g_[r] * NG + s.grp[i_[r]]].y, py[r]);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NS; ++r)
+      if (ok_[r] && i_[r] != 0) {
+        const double2 gf = group_force<R>(k, s, NG, g_[r], A, i_[r], sl_[r], px[r], py[r]);
+        fx[r] += gf.x;
+        fy[r] += gf.y;
+      }
+  };
+  if constexpr (GROUPS) add_group_forces();
 
   const int rows = A / 2;            // half ring; for even A the last row is half length
   const bool even = (A & 1) == 0;
@@ -616,6 +705,7 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel(const sfw_launch L, co
     bool any_live = false;
     for (int g = 0; g < G; ++g) any_live |= (s.dead[g] == 0);
     if (!any_live) break;
+    if constexpr (GROUPS) add_group_forces();
   }
 
   double sw_acc = 0.0;
@@ -635,17 +725,18 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel(const sfw_launch L, co
 // LDS atomics, into two accumulators per agent (received "as i" / "as j") so that
 // each accumulator's summation order is a function of u only.
 // ---------------------------------------------------------------------------
-template <typename R>
+template <typename R, bool GROUPS>
 __global__ void __launch_bounds__(WAVE) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   (void)G_unused;
   const int lane = threadIdx.x;
   const int A = L.A, O = L.O, S = L.S;
-  const lds_layout s(smem, A, A, 1, O);
+  const int NG = GROUPS ? L.NG : 0;
+  const lds_layout s(smem, A, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0);
   const int64_t first_local = blockIdx.x;
   const sfm_consts<R> k = make_consts<R>(L);
   const double inv_O = O > 0 ? 1.0 / O : 0.0;
-  if (!stage_wave(L, s, lane, 1, 1, first_local)) return;
+  if (!stage_wave<GROUPS>(L, s, lane, 1, 1, first_local)) return;
 
   for (int sl = lane; sl < A; sl += WAVE) {
     const double px = L.agent_pos[2 * sl], py = L.agent_pos[2 * sl + 1];
@@ -670,6 +761,28 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel_flat(const sfw_launch 
     s.frj[sl] = double2{0.0, 0.0};
   }
   __syncthreads();
+  auto add_group_forces = [&]() {
+    for (int q = lane; q < NG; q += WAVE) s.gcen[q] = double2{0.0, 0.0};
+    __syncthreads();
+    for (int sl = lane; sl < A; sl += WAVE)
+      if (s.grp[sl] >= 0) {
+        const double2 p = s.pos[sl];
+        atomicAdd(&s.gcen[s.grp[sl]].x, p.x);
+        atomicAdd(&s.gcen[s.grp[sl]].y, p.y);
+      }
+    __syncthreads();
+    for (int sl = lane; sl < A; sl += WAVE)
+      if (sl != 0) {
+        const double2 p = s.pos[sl];
+        const double2 gf = group_force<R>(k, s, NG, 0, A, sl, sl, p.x, p.y);
+        double2 f = s.frc[sl];
+        f.x += gf.x;
+        f.y += gf.y;
+        s.frc[sl] = f;
+      }
+    __syncthreads();
+  };
+  if constexpr (GROUPS) add_group_forces();
 
   const int P = A * (A - 1) / 2;  // unordered pairs
   const int robot_id = s.id[0];
@@ -709,6 +822,7 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel_flat(const sfw_launch 
     }
     __syncthreads();
     if (s.dead[0] != 0) break;
+    if constexpr (GROUPS) add_group_forces();
   }
   double sw_acc = 0.0;
   for (int sl = lane; sl < A; sl += WAVE) sw_acc += s.swp[sl];
@@ -832,8 +946,7 @@ static wave_plan plan_for(int A) {
 
 int sfw_samples_per_wave(int A) { return plan_for(A).G; }
 
-size_t sfw_social_lds_bytes(int A, int O, int precision) {
-  (void)precision;
+size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem) {
   const int G = sfw_samples_per_wave(A);
   const size_t GA = static_cast<size_t>(G) * A;
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
@@ -844,6 +957,8 @@ size_t sfw_social_lds_bytes(int A, int O, int precision) {
   n += up(8 * GA);                          // swp
   n += 3 * up(8 * A);                       // gr, dv, rad
   n += up(4 * A) + up(4 * GA) + up(4 * G);  // id, hasgoal, dead
+  n += up(16 * (NG > 0 ? static_cast<size_t>(G) * NG : 1)) + up(4 * (NG > 0 ? A : 1)) + up(4 * (NG + 1)) +
+       up(4 * (n_grp_mem > 0 ? n_grp_mem : 1));  // gcen, grp, goff, gmem
   return n;
 }
 
@@ -882,11 +997,16 @@ template <typename K> static hipError_t launch_social_as(K kernel, const sfw_lau
 template <typename R> static hipError_t launch_social_typed(const sfw_launch &L, hipStream_t stream) {
   const wave_plan pl = plan_for(L.A);
   const unsigned grid = static_cast<unsigned>((L.chunk_count + pl.G - 1) / pl.G);
-  const size_t lds = sfw_social_lds_bytes(L.A, L.O, L.p.precision);
+  const size_t lds = sfw_social_lds_bytes(L.A, L.O, L.NG, L.n_grp_mem);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  if (pl.flat) return launch_social_as(sfw_social_kernel_flat<R>, L, 1, grid, lds, stream);
-  if (pl.ns == 1) return launch_social_as(sfw_social_kernel<R, 1>, L, pl.G, grid, lds, stream);
-  return launch_social_as(sfw_social_kernel<R, 2>, L, pl.G, grid, lds, stream);
+  if (L.NG > 0) {  // at least one agent carries a group id: kernels with the group pass
+    if (pl.flat) return launch_social_as(sfw_social_kernel_flat<R, true>, L, 1, grid, lds, stream);
+    if (pl.ns == 1) return launch_social_as(sfw_social_kernel<R, 1, true>, L, pl.G, grid, lds, stream);
+    return launch_social_as(sfw_social_kernel<R, 2, true>, L, pl.G, grid, lds, stream);
+  }
+  if (pl.flat) return launch_social_as(sfw_social_kernel_flat<R, false>, L, 1, grid, lds, stream);
+  if (pl.ns == 1) return launch_social_as(sfw_social_kernel<R, 1, false>, L, pl.G, grid, lds, stream);
+  return launch_social_as(sfw_social_kernel<R, 2, false>, L, pl.G, grid, lds, stream);
 }
 
 hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream) {

@@ -35,10 +35,8 @@ def test_call_order_and_argument_errors(hip_mod):
     assert L.sfw_set_footprint(g._h, None, 3) == SFW_ERR_INVALID_ARG
     # outputs are optional
     assert L.sfw_score_grid(g._h, C.byref(rs), lin.ctypes.data, 5, ang.ctypes.data, 9, C.byref(ga), None, None) == SFW_OK
-    # group forces are not built: refused, previous agent set stays in place
-    grouped = (SfwAgent * 2)(scene.agents[0], scene.agents[1])
-    grouped[1].group_id = 4
-    assert L.sfw_set_agents(g._h, C.addressof(grouped), 2, None, 0) == SFW_ERR_UNSUPPORTED
+    # a failed set_agents leaves the previous agent set in place
+    assert L.sfw_set_agents(g._h, None, 2, None, 0) == SFW_ERR_INVALID_ARG
     c1, b1 = g.score_grid(scene.robot_state, lin, ang, scene.goal_args)
     g2 = hip_mod.HipScorer(default_params())
     g2.load_scene(scene)

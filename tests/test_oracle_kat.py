@@ -418,3 +418,84 @@ def test_person_braking_after_goal_pop(oracle_mod):
     o.set_agents((SfwAgent * 2)(robot, _person(900.0, 900.0, 0.5, 0.0, goal=(900.1, 900.0))))
     c, _ = o.score_one(scene.robot_state, 0.4, 0.0, -0.1, scene.goal_args)
     assert c == base
+
+
+# ---------------------------------------------------------------------------
+# group forces (lightsfm computeGroupForce)
+# ---------------------------------------------------------------------------
+def _group_force_numpy(p, agents, idx):
+    """Independent restatement: gaze + coherence + repulsion for agent idx."""
+    a = agents[idx]
+    members = [i for i, b in enumerate(agents) if b.group_id == a.group_id and b.group_id >= 0]
+    if a.group_id < 0 or len(members) < 2:
+        return np.zeros(2)
+    n = len(members)
+    pos = np.array([[b.x, b.y] for b in agents])
+    center = pos[members].sum(axis=0) / n
+    pa = pos[idx]
+    goal = np.array([a.goal_x, a.goal_y])
+    e = goal - pa
+    dd = e / np.linalg.norm(e) if (a.has_goal and np.linalg.norm(e) > a.goal_radius) else np.zeros(2)
+    f = np.zeros(2)
+    com_others = (n * center - pa) / (n - 1)
+    rel = com_others - pa
+    ep = dd @ rel
+    if np.linalg.norm(dd) > 0 and math.acos(ep / (np.linalg.norm(dd) * np.linalg.norm(rel))) > math.pi / 2:
+        f += p.sfm_force_factor_group_gaze * (ep / (dd @ dd)) * dd
+    rel = center - pa
+    f += rel * p.sfm_force_factor_group_coherence * (math.tanh(np.linalg.norm(rel) - (n - 1) / 2) + 1) / 2
+    rep = np.zeros(2)
+    for m in members:
+        if m != idx and np.linalg.norm(pa - pos[m]) < a.radius + agents[m].radius:
+            rep += pa - pos[m]
+    return f + p.sfm_force_factor_group_repulsion * rep
+
+
+def _group_force_oracle(oracle_mod, p, agents, idx):
+    arr = (SfwAgent * len(agents))(*agents)
+    out = np.zeros(2)
+    fn = oracle_mod.lib().sfwo_group_force
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    fn(C.addressof(p), C.addressof(arr), len(agents), idx, out.ctypes.data)
+    return out
+
+
+def test_group_force_hand_case(oracle_mod):
+    """Three people in group 7 on a line, agent 0 walking AWAY from the others
+    (centre of mass behind it -> gaze force pulls it back), agents 1 and 2 overlapping."""
+    p = default_params()
+    a0 = _person(0.0, 0.0, 0.0, 0.0, goal=(-5.0, 0.0), pid=1)
+    a1 = _person(2.0, 0.0, 0.0, 0.0, goal=(10.0, 0.0), pid=2)
+    a2 = _person(2.5, 0.0, 0.0, 0.0, goal=(10.0, 0.0), pid=3)
+    for a in (a0, a1, a2):
+        a.group_id = 7
+    # agent 0: dd = (-1,0); COM of the others = (2.25, 0); ep = -2.25 < 0 -> gaze = 3 * (-2.25) * dd = (6.75, 0)
+    # coherence: centre = (1.5,0), dist 1.5, maxd 1 -> (1.5,0) * 2 * (tanh(0.5)+1)/2
+    exp0 = np.array([6.75 + 1.5 * (math.tanh(0.5) + 1.0), 0.0])
+    assert _group_force_oracle(oracle_mod, p, [a0, a1, a2], 0) == pytest.approx(exp0, rel=1e-14)
+    # agent 1: walks towards +x, the others' COM (1.25,0) is behind it (rel = -0.75): gaze = 3*(-0.75)*(1,0)
+    # coherence: rel = (-0.5,0), dist 0.5 -> (-0.5)*(tanh(-0.5)+1); repulsion: overlaps agent 2 only: (-0.5, 0)
+    exp1 = np.array([-2.25 - 0.5 * (math.tanh(-0.5) + 1.0) - 0.5, 0.0])
+    assert _group_force_oracle(oracle_mod, p, [a0, a1, a2], 1) == pytest.approx(exp1, rel=1e-14)
+    # a lone member or groupId < 0 feels nothing
+    a2.group_id = 8
+    a1.group_id = -1
+    for i in range(3):
+        assert not _group_force_oracle(oracle_mod, p, [a0, a1, a2], i).any()
+
+
+def test_group_force_matches_independent_restatement(oracle_mod):
+    p = default_params()
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        n = int(rng.integers(2, 8))
+        agents = []
+        for i in range(n):
+            x, y = rng.uniform(-2, 2, 2)
+            a = _person(x, y, *rng.uniform(-1, 1, 2), goal=tuple(rng.uniform(-6, 6, 2)), pid=i + 1)
+            a.group_id = int(rng.integers(-1, 3))
+            a.has_goal = int(rng.random() > 0.2)
+            agents.append(a)
+        for i in range(n):
+            got = _group_force_oracle(oracle_mod, p, agents, i)
+            assert got == pytest.approx(_group_force_numpy(p, agents, i), rel=1e-11, abs=1e-13)

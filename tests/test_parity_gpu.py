@@ -353,3 +353,51 @@ def test_f32_forces_mode_within_north_star_tolerance(oracle_mod, hip_mod, name, 
     if gb["index"] != ob["index"]:  # only legal when the oracle itself cannot separate the two
         assert abs(oc[gb["index"]] - ob["cost"]) <= RTOL_NORTH_STAR * ob["cost"]
     assert gb["n_valid"] == ob["n_valid"]
+
+
+# ---------------------------------------------------------------------------
+# group forces: grouped pedestrians, several group shapes
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n_people,seed", [(6, 1), (20, 2), (50, 3), (70, 4)])
+def test_group_forces(oracle_mod, hip_mod, n_people, seed):
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=6, nw=7, n_people=n_people, seed=300 + seed)
+    scene = syn.make_scene(w)
+    rng = np.random.default_rng(seed)
+    ag = scene.agents
+    # groups of 2-4 neighbours walking the same way, one singleton group, the rest ungrouped
+    order = np.argsort([math.atan2(ag[i].y, ag[i].x) for i in range(1, n_people + 1)]) + 1
+    gid, k = 0, 0
+    while k + 1 < min(n_people, 14):
+        size = int(rng.integers(2, 5))
+        members = order[k:k + size]
+        lead = ag[int(members[0])]
+        for m in members:
+            a = ag[int(m)]
+            a.group_id = gid
+            a.x, a.y = lead.x + rng.uniform(-0.5, 0.5), lead.y + rng.uniform(-0.5, 0.5)   # close: repulsion fires
+            # same heading, slightly different speeds: exact relative rest (w = 0) is the one
+            # configuration where the reference's theta is rounding noise (DESIGN.md "deviations")
+            sc = 1.0 + 0.02 * float(rng.uniform(-1, 1))
+            a.vx, a.vy = lead.vx * sc + 0.01 * float(rng.uniform(-1, 1)), lead.vy * sc
+            a.goal_x, a.goal_y = a.x + 2.0 * a.vx, a.y + 2.0 * a.vy
+        gid, k = gid + 1, k + size
+    if n_people > 16:
+        ag[int(order[15])].group_id = 99   # group of one: no group force
+    oc0 = None
+    for prec, rtol in ((0, RTOL_F64), (SFW_PRECISION_F32, RTOL_NORTH_STAR)):
+        p = default_params(precision=prec)
+        o = oracle_mod.OracleScorer(default_params())
+        o.load_scene(scene)
+        g = hip_mod.HipScorer(p)
+        g.load_scene(scene)
+        oc, ob = o.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args, n_threads=8)
+        gc, gb = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+        _assert_parity(oc, ob, gc, gb, rtol)
+        oc0 = oc
+    # the groups matter: the same scene without group ids scores differently
+    for i in range(1, n_people + 1):
+        ag[i].group_id = -1
+    o = oracle_mod.OracleScorer(default_params())
+    o.load_scene(scene)
+    oc_plain, _ = o.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args, n_threads=8)
+    assert not np.allclose(oc0, oc_plain, rtol=1e-6)
