@@ -199,6 +199,15 @@ def run_single_config(workload_name, precision, steps, warmup, dist_ctx):
     }
 
 
+def measured_traffic(workload_name):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return json.load(f).get(workload_name)
+    except (OSError, ValueError):
+        return None
+
+
 def roofline_for(job, k2_ms, precision):
     from social_force_window_planner_amd import synthetic as syn
 
@@ -209,6 +218,7 @@ def roofline_for(job, k2_ms, precision):
     ach = flops_launch / (k2_ms * 1e-3) / 1e12 if k2_ms > 0 else 0.0
     bytes_launch = syn.algorithmic_bytes_per_call(dataclasses.replace(w, nv=len(job.lin)), len(job.scene.footprint))
     hbm = bytes_launch / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
+    tr = measured_traffic(job.workload.name) if (precision == "f64" and not GRID_OVERRIDE) else None
     return {
         "bound": "valu",
         "kernel": "sfw_social_kernel<%s>" % ("float" if precision == "f32" else "double"),
@@ -216,13 +226,15 @@ def roofline_for(job, k2_ms, precision):
         "peak": peak,
         "unit": "TFLOP/s",
         "frac": ach / peak,
-        "traffic": None,
+        "traffic": tr["k2_bytes"] if tr else None,
+        "traffic_note": ("HBM bytes per K2 launch, rocprofv3 PMC passes committed in profiles/r01_traffic.json "
+                         "(the K1->K2 robot-step table; algorithmic bytes are in roofline.hbm)") if tr else None,
         "flops_per_trajectory": flops_traj,
         "kernel_ms": k2_ms,
         "note": "algorithmic flops per SURVEY.md §8d (48 per ordered pair incl. exp/atan2/sqrt as 1 op each); "
                 "non-MFMA vector peak for the dtype",
         "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
-                "traffic": None, "bytes_per_launch": bytes_launch,
+                "traffic": tr["all_kernels_bytes"] if tr else None, "bytes_per_launch": bytes_launch,
                 "note": "non-binding by construction: a few bytes per trajectory (SURVEY.md §8d)"},
     }
 

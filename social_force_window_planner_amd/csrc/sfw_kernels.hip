@@ -243,6 +243,18 @@ template <typename R> struct tiny_of;
 template <> struct tiny_of<double> { static constexpr double v = 1e-300; };
 template <> struct tiny_of<float> { static constexpr float v = 1e-30f; };
 
+// XCD-aware work assignment (MI355X: 8 XCDs with private L2s, block b is observed
+// to run on XCD b % 8 — used for locality only).  Consecutive sample groups share
+// 128-byte lines of the K1->K2 robot-step table (4 records per line); mapping
+// XCD x to the contiguous range [x*q + min(x,r), ...) of groups makes the blocks
+// that share a line hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned n) {
+  constexpr unsigned NX = 8;
+  const unsigned x = b % NX, k = b / NX;
+  const unsigned q = n / NX, r = n % NX;
+  return x * q + (x < r ? x : r) + k;
+}
+
 // Per-launch social-force constants in the force type.
 template <typename R> struct sfm_consts {
   sfwm::poly_consts pc;
@@ -591,7 +603,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   const int GA = G * A;
   const int NG = GROUPS ? L.NG : 0;  // GROUPS=false instantiation: no group code, lean register budget
   const lds_layout s(smem, A, GA, G, O, NG, GROUPS ? L.n_grp_mem : 0);
-  const int64_t first_local = static_cast<int64_t>(blockIdx.x) * G;
+  const int64_t first_local = static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x)) * G;
   const int64_t remain = L.chunk_count - first_local;
   const int Gn = remain < G ? static_cast<int>(remain) : G;
   const sfm_consts<R> k = make_consts<R>(L);
@@ -733,7 +745,7 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel_flat(const sfw_launch 
   const int A = L.A, O = L.O, S = L.S;
   const int NG = GROUPS ? L.NG : 0;
   const lds_layout s(smem, A, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0);
-  const int64_t first_local = blockIdx.x;
+  const int64_t first_local = xcd_contiguous(blockIdx.x, gridDim.x);
   const sfm_consts<R> k = make_consts<R>(L);
   const double inv_O = O > 0 ? 1.0 / O : 0.0;
   if (!stage_wave<GROUPS>(L, s, lane, 1, 1, first_local)) return;
