@@ -1,0 +1,71 @@
+"""Randomized parity sweep: 40 seeded scenes with random agent counts (including
+the wave-packing boundaries 31/32/33, 63/64/65, 127/128/129), step counts,
+footprints, laser points, weights, robot states, way-points and map clutter.
+HIP (f64) vs the CPU oracle at 1e-9; identical sentinel sets and selection."""
+import dataclasses
+import math
+
+import numpy as np
+import pytest
+
+from social_force_window_planner_amd import synthetic as syn
+from social_force_window_planner_amd._abi import default_params
+
+pytestmark = pytest.mark.gpu
+
+COUNTS = [0, 1, 2, 3, 7, 15, 20, 30, 31, 32, 33, 40, 50, 62, 63, 64, 65, 80, 100, 126, 127, 128, 129, 150]
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = COUNTS[seed % len(COUNTS)]
+    steps = int(rng.choice([1, 3, 6, 20, 40, 57]))
+    gran = float(rng.choice([0.025, 0.05, 0.25]))
+    w = dataclasses.replace(
+        syn.WORKLOADS["cfg2"], nv=int(rng.integers(2, 7)), nw=int(rng.integers(2, 8)), n_people=n,
+        map_size=int(rng.choice([120, 200, 333])), sim_time=steps * gran, sim_granularity=gran, seed=2000 + seed,
+        footprint=str(rng.choice(["point", "polygon16", "box"])), n_obstacles=int(rng.choice([0, 0, 5, 40])),
+        n_discs=int(rng.integers(0, 25)))
+    scene = syn.make_scene(w)
+    p = default_params(
+        sim_time=w.sim_time, sim_granularity=gran, max_vel_x=float(rng.uniform(0.4, 1.2)),
+        robot_radius=float(rng.uniform(0.2, 0.5)), social_weight=float(rng.uniform(0.1, 3)),
+        costmap_weight=float(rng.uniform(0, 3)), angle_weight=float(rng.uniform(0, 2)),
+        distance_weight=float(rng.uniform(0.1, 2)), vel_weight=float(rng.uniform(0, 2)))
+    rs = tuple(float(np.float32(v)) for v in (rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-3.1, 3.1),
+                                                rng.uniform(0, 0.8), 0.0, rng.uniform(-0.6, 0.6)))
+    ga = (float(rng.uniform(0.1, 2.0)), 0.0, float(rng.uniform(0.2, 2.0)), float(rng.uniform(-3, 3)),
+          float(rng.uniform(-3, 3)))
+    lin, ang = syn.generalised_sampler(w.nv, w.nw, p.max_vel_x, float(rng.uniform(0.3, 1.6)))
+    # a few people with special properties
+    ag = scene.agents
+    for i in range(1, n + 1):
+        r = rng.random()
+        if r < 0.1:
+            ag[i].has_goal = 0
+        elif r < 0.2:
+            ag[i].desired_velocity = float(rng.uniform(0.3, 2.0))
+        elif r < 0.25:
+            ag[i].goal_radius = float(rng.uniform(0.05, 1.0))
+        if rng.random() < 0.05:
+            ag[i].radius = float(rng.uniform(0.2, 0.5))
+    return scene, p, rs, ga, lin, ang
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scene(oracle_mod, hip_mod, seed):
+    scene, p, rs, ga, lin, ang = _case(seed)
+    o = oracle_mod.OracleScorer(p)
+    o.load_scene(scene)
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    oc, ob = o.score_grid(rs, lin, ang, ga, n_threads=16)
+    gc, gb = g.score_grid(rs, lin, ang, ga)
+    assert np.array_equal(oc < 0, gc < 0), (np.flatnonzero((oc < 0) != (gc < 0)), oc, gc)
+    assert np.array_equal(oc[oc < 0], gc[gc < 0])
+    v = oc >= 0
+    if v.any():
+        rel = np.abs(gc[v] - oc[v]) / np.maximum(np.abs(oc[v]), 1e-300)
+        assert rel.max() <= 1e-9, f"seed {seed}: max rel err {rel.max():.3e}"
+    assert gb["index"] == ob["index"] and gb["n_valid"] == ob["n_valid"]
+    assert gb["vx"] == ob["vx"] and gb["vtheta"] == ob["vtheta"]
