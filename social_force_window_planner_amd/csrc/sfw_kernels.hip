@@ -290,7 +290,7 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   rsqrt_sqrt(l2, rl, il);
   const R sn = fma(ix, uy, -(iy * ux));  // |I| sin(theta)
   const R cs = fma(ix, ux, iy * uy);     // |I| cos(theta)
-  const R theta = atan2_abs(k.pc, fabs(sn), cs);
+  const R theta = atan2_abs(k.pc, fabs(sn), cs, il);  // |(sn,cs)| = |I| since dhat is unit
   const R a = dn * rl * k.neg_inv_gamma;  // -|diff| / B
   const R bt = k.gamma * il * theta;      // B * |theta|
   const R bt2 = bt * bt;

@@ -10,20 +10,18 @@
 
 namespace sfwm {
 
-// atan(q) = q * P(q*q), q in [0,1]; max abs err 3.0e-14
-__device__ constexpr double kAtanP[16] = {
-    9.99999999999944933e-01, -3.33333333306710444e-01, 1.99999997789646333e-01, -1.42857068890334782e-01,
-    1.11109791772467159e-01, -9.08946625885427295e-02, 7.68179614371398145e-02, -6.61281542712686132e-02,
-    5.68091358338733698e-02, -4.69734484941000119e-02, 3.54058579341653967e-02, -2.27526081143878400e-02,
-    1.15690371021628380e-02, -4.25852928310632706e-03, 9.93382185697555542e-04, -1.09195709228515625e-04};
+// 2*atan(t) = t * P(t*t), t = tan(phi/2) in [0, tan(pi/8)]; max abs err 1.9e-14
+__device__ constexpr double kAtanP[9] = {
+    1.99999999999994338e+00, -6.66666666614657344e-01, 3.99999991952324219e-01,
+    -2.85713802188508836e-01, 2.22207562443480111e-01, -1.81566154891948661e-01,
+    1.51262571875266205e-01, -1.17449017943713832e-01, 6.12649577079956778e-02};
 // exp(r), |r| <= ln2/2; max rel err 1.8e-14
 __device__ constexpr double kExpP[10] = {
     1.00000000000001421e+00, 1.00000000000000777e+00, 4.99999999994189259e-01, 1.66666666665346158e-01,
     4.16666670498183830e-02, 8.33333339452756693e-03, 1.38888004009164279e-03, 1.98411575417668925e-04,
     2.48850574964862367e-05, 2.76457905540610794e-06};
-// float atan(q) = q * P(q*q); max abs err 6.4e-8
-__device__ constexpr float kAtanPf[8] = {9.999998820e-01f, -3.333181266e-01f, 1.996696183e-01f, -1.400329018e-01f,
-                                         9.868865458e-02f, -5.882975314e-02f, 2.378051860e-02f, -4.559791986e-03f};
+// float 2*atan(t) = t * P(t*t); max abs err 1.4e-8 + float rounding
+__device__ constexpr float kAtanPf[5] = {1.999999963e+00f, -6.666557114e-01f, 3.994815087e-01f, -2.769682950e-01f, 1.595208338e-01f};
 
 // ---- double ---------------------------------------------------------------
 // Polynomial coefficients pinned to SGPR pairs.  Left to itself hipcc keeps the
@@ -37,10 +35,10 @@ __device__ __forceinline__ double sgpr_const(double c) {
   return c;
 }
 struct poly_consts {
-  double at[16], ex[10];
+  double at[9], ex[10];
   __device__ __forceinline__ poly_consts() {
 #pragma unroll
-    for (int n = 0; n < 16; ++n) at[n] = sgpr_const(kAtanP[n]);
+    for (int n = 0; n < 9; ++n) at[n] = sgpr_const(kAtanP[n]);
 #pragma unroll
     for (int n = 0; n < 10; ++n) ex[n] = sgpr_const(kExpP[n]);
   }
@@ -70,16 +68,18 @@ __device__ __forceinline__ double exp_fast(const poly_consts &pc, double x) {
   for (int n = 8; n >= 0; --n) p = fma(p, r, pc.ex[n]);
   return __builtin_amdgcn_ldexp(p, static_cast<int>(k));  // v_cvt_i32_f64 saturates, ldexp flushes to 0
 }
-// |atan2(y, x)| for y >= 0, result in [0, pi].  (y, x) != (0, 0).
-__device__ __forceinline__ double atan2_abs(const poly_consts &pc, double y, double x) {
+// |atan2(y, x)| for y >= 0, result in [0, pi]; hyp = sqrt(x*x + y*y) > 0 (the
+// caller has it already).  Octant fold to phi in [0, pi/4], then the half-angle
+// t = tan(phi/2) = min / (max + hyp) in [0, tan(pi/8)] keeps the polynomial short.
+__device__ __forceinline__ double atan2_abs(const poly_consts &pc, double y, double x, double hyp) {
   const double ax = fabs(x);
   const double mn = fmin(y, ax), mx = fmax(y, ax);
-  const double q = mn * rcp_nr(fmax(mx, 1e-300));  // (0,0) -> 0, no NaN
-  const double z = q * q;
-  double p = pc.at[15];
+  const double t = mn * rcp_nr(mx + hyp);
+  const double z = t * t;
+  double p = pc.at[8];
 #pragma unroll
-  for (int n = 14; n >= 0; --n) p = fma(p, z, pc.at[n]);
-  double a = p * q;                                   // atan(q), q in [0,1]
+  for (int n = 7; n >= 0; --n) p = fma(p, z, pc.at[n]);
+  double a = p * t;                                   // phi
   a = (y > ax) ? (1.57079632679489661923 - a) : a;    // octant fold
   a = (x < 0.0) ? (3.14159265358979323846 - a) : a;   // half-plane fold
   return a;
@@ -94,15 +94,15 @@ __device__ __forceinline__ float rcp_nr(float x) { return __builtin_amdgcn_rcpf(
 __device__ __forceinline__ float exp_fast(const poly_consts &, float x) {
   return __builtin_amdgcn_exp2f(fmaxf(x * 1.44269504088896340736f, -126.0f));
 }
-__device__ __forceinline__ float atan2_abs(const poly_consts &, float y, float x) {
+__device__ __forceinline__ float atan2_abs(const poly_consts &, float y, float x, float hyp) {
   const float ax = fabsf(x);
   const float mn = fminf(y, ax), mx = fmaxf(y, ax);
-  const float q = mn * rcp_nr(fmaxf(mx, 1e-30f));
-  const float z = q * q;
-  float p = kAtanPf[7];
+  const float t = mn * rcp_nr(mx + hyp);
+  const float z = t * t;
+  float p = kAtanPf[4];
 #pragma unroll
-  for (int n = 6; n >= 0; --n) p = fmaf(p, z, kAtanPf[n]);
-  float a = p * q;
+  for (int n = 3; n >= 0; --n) p = fmaf(p, z, kAtanPf[n]);
+  float a = p * t;
   a = (y > ax) ? (1.57079632679489661923f - a) : a;
   a = (x < 0.0f) ? (3.14159265358979323846f - a) : a;
   return a;

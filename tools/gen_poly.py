@@ -24,10 +24,18 @@ def main():
         q = np.sqrt(np.maximum(z, 0.0))
         return np.where(q > 1e-8, np.arctan(q) / np.where(q > 0, q, 1.0), 1.0 - z / 3.0)
 
-    ca = fit(g, 0.0, 1.0, 15)
-    q = np.linspace(0, 1, 400001)
-    err = np.abs(q * horner(ca, q * q) - np.arctan(q))
-    print("// atan(q) = q * P(q*q), q in [0,1]; max abs err %.2e (float64 Horner)" % err.max())
+    # half-angle form: phi in [0, pi/4] is evaluated as phi = t * P(t*t) with
+    # t = tan(phi/2) = min/(max + hypot) in [0, tan(pi/8)]  (P includes the factor 2)
+    tmax = np.tan(np.pi / 8)
+
+    def g(z):  # noqa: F811
+        t = np.sqrt(np.maximum(z, 0.0))
+        return np.where(t > 1e-8, 2 * np.arctan(t) / np.where(t > 0, t, 1.0), 2.0 - 2 * z / 3.0)
+
+    ca = fit(g, 0.0, tmax * tmax * 1.0001, 8)
+    q = np.linspace(0, tmax, 400001)
+    err = np.abs(q * horner(ca, q * q) - 2 * np.arctan(q))
+    print("// 2*atan(t) = t * P(t*t), t in [0, tan(pi/8)]; max abs err %.2e (float64 Horner)" % err.max())
     print("constexpr double kAtanP[%d] = {" % len(ca))
     print(",\n".join("    %.17e" % v for v in ca) + "};")
     h = np.log(2.0) / 2
@@ -38,8 +46,8 @@ def main():
     print("constexpr double kExpP[%d] = {" % len(ce))
     print(",\n".join("    %.17e" % v for v in ce) + "};")
     # float versions (f32 mode): atan deg 7 in z, exp via v_exp_f32
-    ca32 = fit(g, 0.0, 1.0, 7)
-    err = np.abs(q * horner(ca32, q * q) - np.arctan(q))
+    ca32 = fit(g, 0.0, tmax * tmax * 1.0001, 4)
+    err = np.abs(q * horner(ca32, q * q) - 2 * np.arctan(q))
     print("// float atan: max abs err %.2e" % err.max())
     print("constexpr float kAtanPf[%d] = {" % len(ca32))
     print(",\n".join("    %.9ef" % v for v in ca32) + "};")
