@@ -258,7 +258,7 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned n) {
 // Per-launch social-force constants in the force type.
 template <typename R> struct sfm_consts {
   sfwm::poly_consts pc;
-  R lambda, gamma, neg_inv_gamma, n2, n_prime2, f_social;
+  R lambda, gamma2, neg_inv_gamma, n2, n_prime2, f_social;
   R f_obstacle, inv_sigma;
   double f_desired, inv_tau, dt, rr;
   double f_gaze, f_coherence, f_repulsion;
@@ -276,6 +276,11 @@ template <typename R> struct sfm_consts {
 //   f = Fs * ( -exp(-|diff|/B - (n' B theta)^2) * Ihat
 //              - sign(theta) * exp(-|diff|/B - (n B theta)^2) * leftNormal(Ihat) )
 // cw = w x diff evaluated in double by the caller (exact sign in both modes).
+__device__ __forceinline__ double copysign_from(double mag, double sgn) { return __builtin_copysign(mag, sgn); }
+__device__ __forceinline__ float copysign_from(float mag, double sgn) {
+  return __builtin_copysignf(mag, sgn < 0.0 ? -1.0f : 1.0f);
+}
+
 template <typename R>
 __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R wx, R wy, double cw, R &fx,
                                            R &fy) {
@@ -291,12 +296,12 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   const R sn = fma(ix, uy, -(iy * ux));  // |I| sin(theta)
   const R cs = fma(ix, ux, iy * uy);     // |I| cos(theta)
   const R theta = atan2_abs(k.pc, fabs(sn), cs, il);  // |(sn,cs)| = |I| since dhat is unit
-  const R a = dn * rl * k.neg_inv_gamma;  // -|diff| / B
-  const R bt = k.gamma * il * theta;      // B * |theta|
-  const R bt2 = bt * bt;
+  const R a = dn * rl * k.neg_inv_gamma;        // -|diff| / B
+  const R bt2 = (k.gamma2 * l2) * (theta * theta);  // (B theta)^2, B^2 = gamma^2 |I|^2
   const R ev = exp_fast(k.pc, fma(-k.n_prime2, bt2, a));
   R ea = exp_fast(k.pc, fma(-k.n2, bt2, a));
-  ea = cw > 0.0 ? ea : (cw < 0.0 ? -ea : R(0));  // sign(theta) * exp(...)
+  // sign(theta) * exp(...): sign bit copied from cw, exact zero kept (relative rest)
+  ea = (cw != 0.0) ? copysign_from(ea, cw) : R(0);
   const R sc = rl * k.f_social;
   const R gx = ix * sc, gy = iy * sc;    // Fs * Ihat
   // f = -ev * (Fs Ihat) - ea * leftNormal(Fs Ihat),  leftNormal(x,y) = (-y, x)
@@ -442,7 +447,7 @@ __device__ double2 group_force(const sfm_consts<R> &k, const lds_layout &s, int 
 template <typename R> __device__ __forceinline__ sfm_consts<R> make_consts(const sfw_launch &L) {
   sfm_consts<R> k;
   k.lambda = R(L.p.sfm_lambda);
-  k.gamma = R(L.p.sfm_gamma);
+  k.gamma2 = R(L.p.sfm_gamma * L.p.sfm_gamma);
   k.neg_inv_gamma = R(-1.0 / L.p.sfm_gamma);
   k.n2 = R(L.p.sfm_n * L.p.sfm_n);
   k.n_prime2 = R(L.p.sfm_n_prime * L.p.sfm_n_prime);
