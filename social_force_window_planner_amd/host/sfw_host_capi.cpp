@@ -2,6 +2,7 @@
 // tests (ctypes) can drive SFWPlanner::findBestAction / updatePlan exactly as
 // nav2's controller_server would.  Test plumbing; the product interface is the
 // C++ class in sfw_planner.hpp.
+#include <cmath>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -266,4 +267,53 @@ int32_t sfwh_si_get_agents(void *hv, sfw_agent *out, int32_t cap, double *obs_ou
   *L_out = Ln;
   return A;
 }
+}
+
+// ---------------------------------------------------------------------------
+// transformGlobalPlan shim: plan as (x,y,yaw) triples; the costmap-frame transform
+// is a rigid 2-D transform (tx,ty,yaw).  Returns the number of poses written to
+// out (capacity cap) and the new length of the stored plan in *remaining;
+// -1 / -2 for the two PlannerException cases.
+// ---------------------------------------------------------------------------
+#include "plan_utils.hpp"
+
+extern "C" int32_t sfwh_transform_global_plan(double *plan_xyyaw, int32_t n, const double *robot_xy, uint32_t sx,
+                                              uint32_t sy, double resolution, double tx, double ty, double yaw,
+                                              double *out_xyyaw, int32_t cap, int32_t *remaining) {
+  std::vector<PoseStamped> plan(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) {
+    plan[i].pose.position.x = plan_xyyaw[3 * i];
+    plan[i].pose.position.y = plan_xyyaw[3 * i + 1];
+    plan[i].pose.orientation = quaternionFromYaw(plan_xyyaw[3 * i + 2]);
+  }
+  PoseStamped robot;
+  robot.pose.position.x = robot_xy[0];
+  robot.pose.position.y = robot_xy[1];
+  const double c = std::cos(yaw), s = std::sin(yaw);
+  std::vector<PoseStamped> out;
+  try {
+    out = transformGlobalPlan(plan, robot, sx, sy, resolution, [&](const PoseStamped &in, PoseStamped &o) {
+      o = in;
+      o.pose.position.x = tx + c * in.pose.position.x - s * in.pose.position.y;
+      o.pose.position.y = ty + s * in.pose.position.x + c * in.pose.position.y;
+      o.pose.orientation = quaternionFromYaw(getYaw(in.pose.orientation) + yaw);
+      return true;
+    });
+  } catch (const PlannerException &e) {
+    *remaining = static_cast<int32_t>(plan.size());
+    return std::string(e.what()).find("zero length") != std::string::npos ? -1 : -2;
+  }
+  *remaining = static_cast<int32_t>(plan.size());
+  for (size_t i = 0; i < plan.size(); ++i) {
+    plan_xyyaw[3 * i] = plan[i].pose.position.x;
+    plan_xyyaw[3 * i + 1] = plan[i].pose.position.y;
+    plan_xyyaw[3 * i + 2] = getYaw(plan[i].pose.orientation);
+  }
+  const int m = static_cast<int>(out.size());
+  for (int i = 0; i < m && i < cap; ++i) {
+    out_xyyaw[3 * i] = out[i].pose.position.x;
+    out_xyyaw[3 * i + 1] = out[i].pose.position.y;
+    out_xyyaw[3 * i + 2] = getYaw(out[i].pose.orientation);
+  }
+  return m;
 }
