@@ -63,3 +63,28 @@ def test_two_ranks_on_one_gpu_over_gloo():
     assert d2["global_cmd_vel"]["index"] == d1["cmd_vel"]["index"]
     assert d2["global_cmd_vel"]["vx"] == d1["cmd_vel"]["vx"] and d2["global_cmd_vel"]["vtheta"] == d1["cmd_vel"]["vtheta"]
     assert d2["global_cmd_vel"]["cost"] == d1["cmd_vel"]["cost"]
+
+
+def test_exchange_over_rccl_single_rank():
+    """The all-reduce(min) exchange on the real backend (nccl == RCCL on ROCm) with
+    device tensors; a 1-rank group is all a 1-GPU box can host."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch, torch.distributed as dist
+from social_force_window_planner_amd import multi_gpu
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "%d")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+key = (3.25, -0.7, 0.125, -4242.0)
+r, k, table = multi_gpu.exchange_best(key, dist, 0, 1, device="cuda:0")
+assert r == 0 and k == key and table.shape == (1, 4), (r, k, table)
+r, k, _ = multi_gpu.exchange_best((float("inf"),) * 4, dist, 0, 1, device="cuda:0")
+assert r is None and k is None
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
+dist.destroy_process_group()
+print("rccl-ok")
+''' % _port()
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stderr[-3000:]
