@@ -11,11 +11,16 @@
 //                            once here; the post-step robot states go to HBM as
 //                            a [step][sample] table that K2 streams back.
 //   K2  sfw_social_kernel    one WAVE per G samples: the pedestrians of each
-//                            sample are integrated under the social-force model
+//       sfw_social_kernel_.. sample are integrated under the social-force model
 //                            (lightsfm computeForces/updatePosition, reference
-//                            call sites :592,:594,:697) with all agent state in
-//                            LDS; social work accumulated per lane and reduced
-//                            per sample (reference :613-629, :678-705).
+//                            call sites :592,:594,:697).  Two organisations,
+//                            picked per agent count by plan_for(): register-
+//                            resident agent slots walking the pairs as a half
+//                            ring, or all pairs flattened over the lanes with
+//                            the state in LDS.  Social work accumulated per
+//                            lane and reduced per sample (reference :613-629,
+//                            :678-705).  Group forces only in the GROUPS=true
+//                            instantiations.
 //   K3  sfw_argmin_*         block-wide + grid argmin under the reference's
 //                            selection order (reference :394-414).
 //
@@ -954,7 +959,8 @@ static wave_plan plan_for(int A) {
     const double sc = 0.95 * A / (2.0 * WAVE);
     if (sc >= best_score) { best_score = sc; best = wave_plan{1, 2, false}; }
   }
-  if (const char *e = getenv("SFW_FORCE_FLAT")) {  // tuning overrides
+  static const char *const e = getenv("SFW_FORCE_FLAT");  // tuning override, read once
+  if (e) {
     if (atoi(e) == 1 && A >= 2) best = wave_plan{1, 0, true};
     if (atoi(e) == 0 && A <= 2 * WAVE) best = (A <= WAVE) ? wave_plan{WAVE / A, 1, false} : wave_plan{1, 2, false};
   }
