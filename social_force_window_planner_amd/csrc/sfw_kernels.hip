@@ -214,10 +214,21 @@ __global__ void __launch_bounds__(256) sfw_costmap_scan_kernel(const sfw_launch 
   const int S = L.S;
   double cm = 0.0;
   int n_ok = 0;
-  for (; n_ok < S; ++n_ok) {
-    const double fc = static_cast<double>(L.fcode[static_cast<int64_t>(n_ok) * L.rstep_stride + local]);
-    if (fc >= 254.0 || fc < 0) break;
-    cm += fc / 255.0;
+  bool stopped = false;
+  // codes are fetched 8 at a time (independent loads in flight) and consumed in step order
+  for (int base = 0; base < S && !stopped; base += 8) {
+    int16_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = (base + j < S) ? L.fcode[static_cast<int64_t>(base + j) * L.rstep_stride + local] : int16_t(-1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double fc = static_cast<double>(v[j]);
+      if (!stopped && base + j < S) {
+        if (fc >= 254.0 || fc < 0) stopped = true;
+        else { cm += fc / 255.0; ++n_ok; }
+      }
+    }
   }
   if (L.n_points) *L.n_points = n_ok;
   if (n_ok < S) {
