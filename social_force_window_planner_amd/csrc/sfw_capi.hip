@@ -37,6 +37,47 @@ template <typename T> struct dev_buf {
   }
 };
 
+// Pinned host staging area for one logical upload.  The caller's buffer is copied
+// here synchronously (so it may be freed or reused on return) and the H2D copy is
+// enqueued on the handle's stream; `done` guards the area against being rewritten
+// while that copy is still pending.  No stream synchronisation on the hot path.
+struct pinned_buf {
+  char *p = nullptr;
+  size_t cap = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+  hipError_t wait() {
+    if (!pending) return hipSuccess;
+    pending = false;
+    return hipEventSynchronize(done);
+  }
+  hipError_t reserve(size_t bytes) {
+    hipError_t e = wait();
+    if (e != hipSuccess) return e;
+    if (!done && (e = hipEventCreateWithFlags(&done, hipEventDisableTiming)) != hipSuccess) return e;
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 4 + 256;
+    e = hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  hipError_t mark(hipStream_t s) {
+    pending = true;
+    return hipEventRecord(done, s);
+  }
+  void release() {
+    (void)wait();
+    if (p) (void)hipHostFree(p);
+    if (done) (void)hipEventDestroy(done);
+    p = nullptr;
+    cap = 0;
+    done = nullptr;
+  }
+};
+
 }  // namespace
 
 struct sfw_planner_s {
@@ -79,6 +120,7 @@ struct sfw_planner_s {
   dev_buf<double> points;
   dev_buf<int32_t> n_points;
   size_t table_budget_bytes = size_t(2) << 30;  // K1->K2 robot-step table per chunk
+  pinned_buf pin_map, pin_fp, pin_agents, pin_grid, pin_out;
 };
 
 namespace {
@@ -169,10 +211,13 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   SFW_HIP(h, h->angvels.reserve(nw));
   h->h_lin.assign(lin, lin + nv);
   h->h_ang.assign(ang, ang + nw);
-  SFW_HIP(h, hipMemcpyAsync(h->linvels.p, h->h_lin.data(), sizeof(double) * nv, hipMemcpyHostToDevice,
-                            h->stream));
-  SFW_HIP(h, hipMemcpyAsync(h->angvels.p, h->h_ang.data(), sizeof(double) * nw, hipMemcpyHostToDevice,
-                            h->stream));
+  SFW_HIP(h, h->pin_grid.reserve(sizeof(double) * (static_cast<size_t>(nv) + nw)));
+  std::memcpy(h->pin_grid.p, lin, sizeof(double) * nv);
+  std::memcpy(h->pin_grid.p + sizeof(double) * nv, ang, sizeof(double) * nw);
+  SFW_HIP(h, hipMemcpyAsync(h->linvels.p, h->pin_grid.p, sizeof(double) * nv, hipMemcpyHostToDevice, h->stream));
+  SFW_HIP(h, hipMemcpyAsync(h->angvels.p, h->pin_grid.p + sizeof(double) * nv, sizeof(double) * nw,
+                            hipMemcpyHostToDevice, h->stream));
+  SFW_HIP(h, h->pin_grid.mark(h->stream));
   h->nv = nv;
   h->nw = nw;
   h->rs = *rs;
@@ -344,6 +389,11 @@ int sfw_destroy(sfw_handle h) {
   h->sel.release();
   h->points.release();
   h->n_points.release();
+  h->pin_map.release();
+  h->pin_fp.release();
+  h->pin_agents.release();
+  h->pin_grid.release();
+  h->pin_out.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -367,10 +417,12 @@ int sfw_set_costmap(sfw_handle h, const uint8_t *cells, uint32_t size_x, uint32_
     return fail(h, SFW_ERR_INVALID_ARG, "set_costmap: null cells, zero size or non-positive resolution");
   SFW_HIP(h, hipSetDevice(h->device));
   const size_t n = static_cast<size_t>(size_x) * size_y;
-  SFW_HIP(h, hipStreamSynchronize(h->stream));  // a previous launch may still read the old snapshot
+  // stream order keeps a launch already in flight on the old snapshot; no synchronisation
   SFW_HIP(h, h->cells.reserve(n));
-  SFW_HIP(h, hipMemcpyAsync(h->cells.p, cells, n, hipMemcpyHostToDevice, h->stream));
-  SFW_HIP(h, hipStreamSynchronize(h->stream));  // caller may free `cells` on return
+  SFW_HIP(h, h->pin_map.reserve(n));
+  std::memcpy(h->pin_map.p, cells, n);
+  SFW_HIP(h, hipMemcpyAsync(h->cells.p, h->pin_map.p, n, hipMemcpyHostToDevice, h->stream));
+  SFW_HIP(h, h->pin_map.mark(h->stream));
   h->size_x = size_x;
   h->size_y = size_y;
   h->origin_x = origin_x;
@@ -384,11 +436,13 @@ int sfw_set_footprint(sfw_handle h, const double *xy, int32_t K) {
   if (!h) return SFW_ERR_INVALID_ARG;
   if (K < 0 || (K > 0 && !xy)) return fail(h, SFW_ERR_INVALID_ARG, "set_footprint: bad arguments");
   SFW_HIP(h, hipSetDevice(h->device));
-  SFW_HIP(h, hipStreamSynchronize(h->stream));
   SFW_HIP(h, h->footprint.reserve(static_cast<size_t>(2) * (K > 0 ? K : 1)));
   if (K > 0) {
-    SFW_HIP(h, hipMemcpyAsync(h->footprint.p, xy, sizeof(double) * 2 * K, hipMemcpyHostToDevice, h->stream));
-    SFW_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t bytes = sizeof(double) * 2 * K;
+    SFW_HIP(h, h->pin_fp.reserve(bytes));
+    std::memcpy(h->pin_fp.p, xy, bytes);
+    SFW_HIP(h, hipMemcpyAsync(h->footprint.p, h->pin_fp.p, bytes, hipMemcpyHostToDevice, h->stream));
+    SFW_HIP(h, h->pin_fp.mark(h->stream));
   }
   h->K = K;
   return SFW_OK;
@@ -399,9 +453,33 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   if (A < 0 || O < 0 || (A > 0 && !agents) || (O > 0 && !obstacles_xy))
     return fail(h, SFW_ERR_INVALID_ARG, "set_agents: bad arguments");
   SFW_HIP(h, hipSetDevice(h->device));
-  SFW_HIP(h, hipStreamSynchronize(h->stream));
-  std::vector<double> pos(2 * static_cast<size_t>(A > 0 ? A : 1)), vel(pos.size());
-  std::vector<sfw_agent_const> cst(static_cast<size_t>(A > 0 ? A : 1));
+  const size_t An = static_cast<size_t>(A > 0 ? A : 1), On = static_cast<size_t>(O > 0 ? O : 1);
+  // groups: dense index in order of first appearance, CSR member lists in agent order
+  std::vector<int32_t> grp(An, -1), ids, off(1, 0), mem;
+  for (int i = 0; i < A; ++i) {
+    if (agents[i].group_id < 0) continue;
+    size_t q = 0;
+    while (q < ids.size() && ids[q] != agents[i].group_id) ++q;
+    if (q == ids.size()) ids.push_back(agents[i].group_id);
+    grp[i] = static_cast<int32_t>(q);
+  }
+  for (size_t q = 0; q < ids.size(); ++q) {
+    for (int i = 0; i < A; ++i)
+      if (grp[i] == static_cast<int32_t>(q)) mem.push_back(i);
+    off.push_back(static_cast<int32_t>(mem.size()));
+  }
+  const int n_mem = off.back();
+  if (mem.empty()) mem.push_back(0);
+  // one pinned arena: pos | vel | const | obstacles | grp | off | mem  (16-byte aligned parts)
+  auto up16 = [](size_t b) { return (b + 15) & ~size_t(15); };
+  const size_t o_pos = 0, o_vel = o_pos + up16(16 * An), o_cst = o_vel + up16(16 * An),
+               o_obs = o_cst + up16(sizeof(sfw_agent_const) * An), o_grp = o_obs + up16(16 * On),
+               o_off = o_grp + up16(4 * An), o_mem = o_off + up16(4 * off.size()),
+               total = o_mem + up16(4 * mem.size());
+  SFW_HIP(h, h->pin_agents.reserve(total));
+  char *base = h->pin_agents.p;
+  double *pos = reinterpret_cast<double *>(base + o_pos), *vel = reinterpret_cast<double *>(base + o_vel);
+  sfw_agent_const *cst = reinterpret_cast<sfw_agent_const *>(base + o_cst);
   for (int i = 0; i < A; ++i) {
     pos[2 * i] = agents[i].x;
     pos[2 * i + 1] = agents[i].y;
@@ -416,44 +494,30 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
     c.id = agents[i].id;
     c.has_goal = agents[i].has_goal ? 1 : 0;
   }
-  // groups: dense index in order of first appearance, CSR member lists in agent order
-  std::vector<int32_t> grp(static_cast<size_t>(A > 0 ? A : 1), -1), ids, off(1, 0), mem;
-  for (int i = 0; i < A; ++i) {
-    if (agents[i].group_id < 0) continue;
-    size_t q = 0;
-    while (q < ids.size() && ids[q] != agents[i].group_id) ++q;
-    if (q == ids.size()) ids.push_back(agents[i].group_id);
-    grp[i] = static_cast<int32_t>(q);
-  }
-  for (size_t q = 0; q < ids.size(); ++q) {
-    for (int i = 0; i < A; ++i)
-      if (grp[i] == static_cast<int32_t>(q)) mem.push_back(i);
-    off.push_back(static_cast<int32_t>(mem.size()));
-  }
-  if (mem.empty()) mem.push_back(0);
-  SFW_HIP(h, h->agent_grp.reserve(grp.size()));
+  if (O > 0) std::memcpy(base + o_obs, obstacles_xy, sizeof(double) * 2 * O);
+  std::memcpy(base + o_grp, grp.data(), 4 * grp.size());
+  std::memcpy(base + o_off, off.data(), 4 * off.size());
+  std::memcpy(base + o_mem, mem.data(), 4 * mem.size());
+  SFW_HIP(h, h->agent_pos.reserve(2 * An));
+  SFW_HIP(h, h->agent_vel.reserve(2 * An));
+  SFW_HIP(h, h->agent_c.reserve(An));
+  SFW_HIP(h, h->obstacles.reserve(2 * On));
+  SFW_HIP(h, h->agent_grp.reserve(An));
   SFW_HIP(h, h->grp_off.reserve(off.size()));
   SFW_HIP(h, h->grp_mem.reserve(mem.size()));
-  SFW_HIP(h, hipMemcpyAsync(h->agent_grp.p, grp.data(), sizeof(int32_t) * grp.size(), hipMemcpyHostToDevice, h->stream));
-  SFW_HIP(h, hipMemcpyAsync(h->grp_off.p, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice, h->stream));
-  SFW_HIP(h, hipMemcpyAsync(h->grp_mem.p, mem.data(), sizeof(int32_t) * mem.size(), hipMemcpyHostToDevice, h->stream));
-  SFW_HIP(h, hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
+  auto h2d = [&](void *dst, size_t o, size_t bytes) {
+    return bytes ? hipMemcpyAsync(dst, base + o, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
+  };
+  SFW_HIP(h, h2d(h->agent_pos.p, o_pos, 16 * static_cast<size_t>(A)));
+  SFW_HIP(h, h2d(h->agent_vel.p, o_vel, 16 * static_cast<size_t>(A)));
+  SFW_HIP(h, h2d(h->agent_c.p, o_cst, sizeof(sfw_agent_const) * static_cast<size_t>(A)));
+  SFW_HIP(h, h2d(h->obstacles.p, o_obs, 16 * static_cast<size_t>(O)));
+  SFW_HIP(h, h2d(h->agent_grp.p, o_grp, 4 * static_cast<size_t>(A)));
+  SFW_HIP(h, h2d(h->grp_off.p, o_off, 4 * off.size()));
+  SFW_HIP(h, h2d(h->grp_mem.p, o_mem, 4 * mem.size()));
+  SFW_HIP(h, h->pin_agents.mark(h->stream));
   h->NG = static_cast<int>(ids.size());
-  h->n_grp_mem = off.back();
-  SFW_HIP(h, h->agent_pos.reserve(pos.size()));
-  SFW_HIP(h, h->agent_vel.reserve(vel.size()));
-  SFW_HIP(h, h->agent_c.reserve(cst.size()));
-  SFW_HIP(h, h->obstacles.reserve(static_cast<size_t>(2) * (O > 0 ? O : 1)));
-  SFW_HIP(h, hipMemcpyAsync(h->agent_pos.p, pos.data(), sizeof(double) * pos.size(), hipMemcpyHostToDevice,
-                            h->stream));
-  SFW_HIP(h, hipMemcpyAsync(h->agent_vel.p, vel.data(), sizeof(double) * vel.size(), hipMemcpyHostToDevice,
-                            h->stream));
-  SFW_HIP(h, hipMemcpyAsync(h->agent_c.p, cst.data(), sizeof(sfw_agent_const) * cst.size(),
-                            hipMemcpyHostToDevice, h->stream));
-  if (O > 0)
-    SFW_HIP(h, hipMemcpyAsync(h->obstacles.p, obstacles_xy, sizeof(double) * 2 * O, hipMemcpyHostToDevice,
-                              h->stream));
-  SFW_HIP(h, hipStreamSynchronize(h->stream));
+  h->n_grp_mem = n_mem;
   h->A = A;
   h->O = O;
   return SFW_OK;
@@ -478,11 +542,13 @@ int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out, sfw_best
   if (!h->launched) return fail(h, SFW_ERR_STATE, "grid_fetch before grid_launch");
   SFW_HIP(h, hipSetDevice(h->device));
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
-  sfw_sel s;
+  SFW_HIP(h, h->pin_out.reserve(sizeof(sfw_sel)));
   if (costs_out)
     SFW_HIP(h, hipMemcpyAsync(costs_out, h->costs.p, sizeof(double) * T, hipMemcpyDeviceToHost, h->stream));
-  SFW_HIP(h, hipMemcpyAsync(&s, h->sel.p, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+  SFW_HIP(h, hipMemcpyAsync(h->pin_out.p, h->sel.p, sizeof(sfw_sel), hipMemcpyDeviceToHost, h->stream));
   SFW_HIP(h, hipStreamSynchronize(h->stream));
+  sfw_sel s;
+  std::memcpy(&s, h->pin_out.p, sizeof(s));
   sel_to_best(h, s, best_out, key_out);
   return SFW_OK;
 }
