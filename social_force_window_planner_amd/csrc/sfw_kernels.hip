@@ -592,16 +592,19 @@ __device__ __forceinline__ void finish_wave(const sfw_launch &L, const lds_layou
       else if (d == 2) { L.costs[t] = SFW_COST_INVALID; L.status[t] = SFW_ST_INVALID; }
     }
   } else {
-    // G > 1: every lane owns slots of possibly different samples; per-slot sums
-    // were accumulated into swp[] and are added per sample in agent order.
+    // G > 1 (GA <= 64): per-slot sums were written to swp[]; every sample is reduced
+    // with the SAME 64-lane shuffle tree as the G == 1 case (lanes >= A contribute 0),
+    // so a sample's cost does not depend on how the wave was organised.
     __syncthreads();
-    if (lane < Gn) {
-      double v = 0.0;
-      for (int i = 0; i < A; ++i) v += s.swp[lane * A + i];
-      const int64_t t = L.chunk_begin + first_local + lane;
-      const int d = s.dead[lane];
-      if (d == 0) L.costs[t] = L.base_cost[t] + L.p.social_weight * v;
-      else if (d == 2) { L.costs[t] = SFW_COST_INVALID; L.status[t] = SFW_ST_INVALID; }
+    for (int g = 0; g < Gn; ++g) {
+      double v = (lane < A) ? s.swp[g * A + lane] : 0.0;
+      for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+      if (lane == 0) {
+        const int64_t t = L.chunk_begin + first_local + g;
+        const int d = s.dead[g];
+        if (d == 0) L.costs[t] = L.base_cost[t] + L.p.social_weight * v;
+        else if (d == 2) { L.costs[t] = SFW_COST_INVALID; L.status[t] = SFW_ST_INVALID; }
+      }
     }
   }
   (void)GA;
