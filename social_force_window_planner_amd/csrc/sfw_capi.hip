@@ -255,7 +255,7 @@ int launch_common(sfw_handle h) {
   int64_t chunk = static_cast<int64_t>(std::min(h->rstep.cap, std::min(h->frame.cap, h->fcode.cap)) / S);
   if (chunk > T) chunk = T;
   if (chunk < 1) return fail(h, SFW_ERR_STATE, "robot-step table too small (params changed after stage?)");
-  const size_t lds = sfw_social_lds_bytes(h->A, h->O, h->NG, h->n_grp_mem);
+  const size_t lds = sfw_social_lds_bytes(h->A, h->O, h->NG, h->n_grp_mem, chunk);
   if (h->A > 0 && lds > 160 * 1024)
     return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
   SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));

@@ -100,7 +100,7 @@ hipError_t sfw_launch_argmin(const double *costs, const double *linvels, const d
                              int32_t nw, int64_t T, int64_t index_base, sfw_sel *partials,
                              sfw_sel *out, hipStream_t stream);
 // Samples handled by one wave of the social kernel for A agents.
-int sfw_samples_per_wave(int A);
-size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem);
+int sfw_samples_per_wave(int A, int64_t T);
+size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T);
 
 #endif  // SFW_DEVICE_H_

@@ -959,8 +959,13 @@ sfw_argmin_stage2(const sfw_sel *partials, int n, sfw_sel *out) {
 //   reg  NS=2 : one sample, lanes used A/128 (64 < A <= 128), slightly lower occupancy
 //   flat      : one sample, ~100 % of the lanes but ~20 % more instructions per pair
 // pick the largest utilisation x efficiency.
+//   few samples (T <= 4096): flat, one sample per wave — the GPU is not full, so the
+//   shorter per-step critical path (P/64 iterations instead of A/2 rows) wins
+//   (A = 21: K2 0.10 ms vs 0.17 ms at 45..1024 samples, crossover ~4096).
+// All organisations produce bit-identical costs (tools/kernel_equiv.py), so the choice
+// never shows in the results.
 struct wave_plan { int G; int ns; bool flat; };
-static wave_plan plan_for(int A) {
+static wave_plan plan_for(int A, int64_t T) {
   wave_plan best{1, 0, true};
   if (A <= 0) return wave_plan{1, 1, false};
   const int P = A * (A - 1) / 2;
@@ -973,6 +978,7 @@ static wave_plan plan_for(int A) {
     const double sc = 0.95 * A / (2.0 * WAVE);
     if (sc >= best_score) { best_score = sc; best = wave_plan{1, 2, false}; }
   }
+  if (T <= 4096 && A >= 2) best = wave_plan{1, 0, true};
   static const char *const e = getenv("SFW_FORCE_FLAT");  // tuning override, read once
   if (e) {
     if (atoi(e) == 1 && A >= 2) best = wave_plan{1, 0, true};
@@ -981,10 +987,10 @@ static wave_plan plan_for(int A) {
   return best;
 }
 
-int sfw_samples_per_wave(int A) { return plan_for(A).G; }
+int sfw_samples_per_wave(int A, int64_t T) { return plan_for(A, T).G; }
 
-size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem) {
-  const int G = sfw_samples_per_wave(A);
+size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T) {
+  const int G = sfw_samples_per_wave(A, T);
   const size_t GA = static_cast<size_t>(G) * A;
   auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
   size_t n = 0;
@@ -1032,9 +1038,9 @@ template <typename K> static hipError_t launch_social_as(K kernel, const sfw_lau
 }
 
 template <typename R> static hipError_t launch_social_typed(const sfw_launch &L, hipStream_t stream) {
-  const wave_plan pl = plan_for(L.A);
+  const wave_plan pl = plan_for(L.A, L.chunk_count);
   const unsigned grid = static_cast<unsigned>((L.chunk_count + pl.G - 1) / pl.G);
-  const size_t lds = sfw_social_lds_bytes(L.A, L.O, L.NG, L.n_grp_mem);
+  const size_t lds = sfw_social_lds_bytes(L.A, L.O, L.NG, L.n_grp_mem, L.chunk_count);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (L.NG > 0) {  // at least one agent carries a group id: kernels with the group pass
     if (pl.flat) return launch_social_as(sfw_social_kernel_flat<R, true>, L, 1, grid, lds, stream);
