@@ -218,6 +218,16 @@ int sfw_last_launch_ms(sfw_handle h, int32_t which, float *ms_out);
  * launch (Trajectory points for RViz markers, :366-374). */
 int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth,
                     int32_t points_cap, int32_t *n_points);
+/* The same for `count` consecutive samples starting at `first` in one call (the
+ * reference fills one RViz marker per sample every cycle, :347-386).
+ * points_xyth: count x steps x 3 doubles (steps = num_steps of the params),
+ * n_points: count ints = poses the reference's Trajectory would hold: all of them
+ * for a valid sample, those before the first illegal footprint pose, or 0..i for a
+ * sample rejected by pedestrian contact at step i (0 for the (0,0) sample).
+ * Corner not reproduced: a sample that is illegal on the costmap at pose j AND
+ * would have touched a pedestrian at an earlier step i reports j poses (the
+ * pedestrians of costmap-rejected samples are never integrated). */
+int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *points_xyth, int32_t *n_points);
 /* Raw HIP stream (hipStream_t) the handle launches on, for callers that want
  * to record their own events. */
 void *sfw_stream(sfw_handle h);

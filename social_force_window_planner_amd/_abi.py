@@ -149,6 +149,7 @@ EXPORTED_SYMBOLS = (
     "sfw_grid_fetch",
     "sfw_last_launch_ms",
     "sfw_grid_points",
+    "sfw_grid_points_batch",
     "sfw_stream",
 )
 

@@ -111,7 +111,7 @@ struct sfw_planner_s {
   bool staged = false, launched = false;
 
   // per-sample outputs + per-chunk table
-  dev_buf<int32_t> status;
+  dev_buf<int32_t> status, coll_step;
   dev_buf<double> base_cost, costs;
   dev_buf<sfw_robot_step> rstep;
   dev_buf<sfw_pose_frame> frame;
@@ -192,6 +192,7 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.status = h->status.p;
   L.base_cost = h->base_cost.p;
   L.costs = h->costs.p;
+  L.coll_step = h->coll_step.p;
   L.rstep = h->rstep.p;
   L.frame = h->frame.p;
   L.fcode = h->fcode.p;
@@ -227,6 +228,7 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   h->index_base = index_base;
   const int64_t T = static_cast<int64_t>(nv) * nw;
   SFW_HIP(h, h->status.reserve(T));
+  SFW_HIP(h, h->coll_step.reserve(T));
   SFW_HIP(h, h->base_cost.reserve(T));
   SFW_HIP(h, h->costs.reserve(T));
   SFW_HIP(h, h->partials.reserve(sfw_argmin_partials(T)));
@@ -380,6 +382,7 @@ int sfw_destroy(sfw_handle h) {
   h->linvels.release();
   h->angvels.release();
   h->status.release();
+  h->coll_step.release();
   h->base_cost.release();
   h->costs.release();
   h->rstep.release();
@@ -577,9 +580,12 @@ int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp, doubl
   SFW_HIP(h, sfw_launch_rollout(L, h->stream));
   SFW_HIP(h, sfw_launch_social(L, h->stream));
   int32_t n = 0;
+  int32_t coll = -1;
   SFW_HIP(h, hipMemcpyAsync(cost_out, h->costs.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   SFW_HIP(h, hipMemcpyAsync(&n, h->n_points.p, sizeof(n), hipMemcpyDeviceToHost, h->stream));
+  SFW_HIP(h, hipMemcpyAsync(&coll, h->coll_step.p, sizeof(coll), hipMemcpyDeviceToHost, h->stream));
   SFW_HIP(h, hipStreamSynchronize(h->stream));
+  if (coll >= 0 && coll + 1 < n) n = coll + 1;  // rejected by contact at step `coll`: poses 0..coll were added
   if (n_points) *n_points = n;
   if (points_xyth && points_cap > 0 && n > 0) {
     const int m = n < points_cap ? n : points_cap;
@@ -607,47 +613,51 @@ int sfw_last_launch_ms(sfw_handle h, int32_t which, float *ms_out) {
   return SFW_OK;
 }
 
-int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth, int32_t points_cap, int32_t *n_points) {
+int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *points_xyth, int32_t *n_points) {
   if (!h) return SFW_ERR_INVALID_ARG;
   if (!h->staged) return fail(h, SFW_ERR_STATE, "grid_points before grid_stage");
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
-  if (index < 0 || index >= T || !points_xyth || points_cap <= 0)
-    return fail(h, SFW_ERR_INVALID_ARG, "grid_points: bad index or buffer");
+  if (first < 0 || count <= 0 || first + count > T || !points_xyth || !n_points)
+    return fail(h, SFW_ERR_INVALID_ARG, "grid_points: bad range or buffer");
   SFW_HIP(h, hipSetDevice(h->device));
   const int S = num_steps_of(h->params);
-  SFW_HIP(h, h->points.reserve(static_cast<size_t>(3) * S));
-  SFW_HIP(h, h->n_points.reserve(1));
-  // Re-run K1 for that one sample into scratch outputs so the grid results stay intact.
+  const size_t n = static_cast<size_t>(count);
+  SFW_HIP(h, h->points.reserve(3 * static_cast<size_t>(S) * n));
+  SFW_HIP(h, h->n_points.reserve(n));
+  // Re-run K1 for those samples into scratch outputs so the grid results stay intact.
   dev_buf<int32_t> st;
   dev_buf<double> bc, cs;
   dev_buf<sfw_robot_step> tb;
   dev_buf<sfw_pose_frame> fr;
   dev_buf<int16_t> fco;
-  SFW_HIP(h, st.reserve(T));
-  SFW_HIP(h, bc.reserve(T));
-  SFW_HIP(h, cs.reserve(T));
-  SFW_HIP(h, tb.reserve(S));
-  SFW_HIP(h, fr.reserve(S));
-  SFW_HIP(h, fco.reserve(S));
-  sfw_launch L;
-  fill_launch(h, L, index, 1, 1);
-  L.status = st.p;
-  L.base_cost = bc.p;
-  L.costs = cs.p;
-  L.rstep = tb.p;
-  L.frame = fr.p;
-  L.fcode = fco.p;
-  L.skip_zero_sample = 0;
-  L.points = h->points.p;
-  L.n_points = h->n_points.p;
-  hipError_t e = sfw_launch_rollout(L, h->stream);
-  int32_t n = 0;
-  if (e == hipSuccess) e = hipMemcpyAsync(&n, h->n_points.p, sizeof(n), hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  if (e == hipSuccess && n > 0) {
-    const int m = n < points_cap ? n : points_cap;
-    e = hipMemcpy(points_xyth, h->points.p, sizeof(double) * 3 * m, hipMemcpyDeviceToHost);
+  hipError_t e = st.reserve(T);
+  if (e == hipSuccess) e = bc.reserve(T);
+  if (e == hipSuccess) e = cs.reserve(T);
+  if (e == hipSuccess) e = tb.reserve(static_cast<size_t>(S) * n);
+  if (e == hipSuccess) e = fr.reserve(static_cast<size_t>(S) * n);
+  if (e == hipSuccess) e = fco.reserve(static_cast<size_t>(S) * n);
+  if (e == hipSuccess) {
+    sfw_launch L;
+    fill_launch(h, L, first, count, count);
+    L.status = st.p;
+    L.base_cost = bc.p;
+    L.costs = cs.p;
+    L.coll_step = nullptr;  // keep the launch's contact steps
+    L.rstep = tb.p;
+    L.frame = fr.p;
+    L.fcode = fco.p;
+    L.points = h->points.p;
+    L.n_points = h->n_points.p;
+    e = sfw_launch_rollout(L, h->stream);
   }
+  std::vector<int32_t> coll(n, -1);
+  if (e == hipSuccess && h->launched)
+    e = hipMemcpyAsync(coll.data(), h->coll_step.p + first, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(n_points, h->n_points.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(points_xyth, h->points.p, sizeof(double) * 3 * S * n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   st.release();
   bc.release();
   cs.release();
@@ -655,6 +665,21 @@ int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth, int32_t po
   fr.release();
   fco.release();
   if (e != hipSuccess) return hip_fail(h, e, "grid_points");
+  // a trajectory rejected by contact at step i holds the poses 0..i (addPoint precedes the test, ref :578, :613-627)
+  for (size_t i = 0; i < n; ++i)
+    if (coll[i] >= 0 && coll[i] + 1 < n_points[i]) n_points[i] = coll[i] + 1;
+  return SFW_OK;
+}
+
+int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth, int32_t points_cap, int32_t *n_points) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  if (!points_xyth || points_cap <= 0) return fail(h, SFW_ERR_INVALID_ARG, "grid_points: bad index or buffer");
+  const int S = num_steps_of(h->params);
+  std::vector<double> tmp(static_cast<size_t>(3) * S);
+  int32_t n = 0;
+  if (int rc = sfw_grid_points_batch(h, index, 1, tmp.data(), &n)) return rc;
+  const int m = n < points_cap ? n : points_cap;
+  std::memcpy(points_xyth, tmp.data(), sizeof(double) * 3 * static_cast<size_t>(m));
   if (n_points) *n_points = n;
   return SFW_OK;
 }

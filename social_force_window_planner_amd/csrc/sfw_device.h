@@ -71,14 +71,15 @@ struct sfw_launch {
   int32_t *status;       // T
   double *base_cost;     // T : vel + distance + angle + costmap terms (ref :663-666)
   double *costs;         // T : final cost or sentinel
+  int32_t *coll_step;    // T : step at which a pedestrian touched the robot (ref :613-627), -1 if none; nullable
   // per-chunk table, indexed [step][local sample]
   sfw_robot_step *rstep;
   sfw_pose_frame *frame;
   int16_t *fcode;        // footprint cost per (step, sample): -3,-2,-1 or 0..253
   int64_t rstep_stride;  // samples per step row
-  // optional Trajectory-points dump (x,y,theta per pre-step pose), one sample
-  double *points;        // nullable, 3*S doubles
-  int32_t *n_points;     // nullable
+  // optional Trajectory-points dump (x,y,theta per pre-step pose) of the chunk's samples
+  double *points;        // nullable, chunk_count x S x 3 doubles
+  int32_t *n_points;     // nullable, chunk_count ints
 };
 
 // Selection record (see sfw_best / sfw_best_key in the public header).

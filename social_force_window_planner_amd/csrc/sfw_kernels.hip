@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
     return;
   }
   L.status[t] = SFW_ST_VALID;  // K1c downgrades it if a step is illegal
+  if (L.coll_step) L.coll_step[t] = -1;
   double x_i = L.rs.x, y_i = L.rs.y, th_i = L.rs.theta;
   double vx_i = L.rs.vx, vy_i = L.rs.vy, vth_i = L.rs.vtheta;
   const int S = L.S;
@@ -161,9 +162,10 @@ __global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
     f.x = x_i; f.y = y_i; f.c = c; f.s = s;
     L.frame[static_cast<int64_t>(i) * L.rstep_stride + local] = f;
     if (L.points) {                                       // ref :578
-      L.points[3 * i] = x_i;
-      L.points[3 * i + 1] = y_i;
-      L.points[3 * i + 2] = th_i;
+      double *pt = L.points + (local * S + i) * 3;
+      pt[0] = x_i;
+      pt[1] = y_i;
+      pt[2] = th_i;
     }
     vx_i = new_velocity(vx_samp, vx_i, L.ga.acc_x, dt);   // ref :581-583
     vy_i = new_velocity(vy_samp, vy_i, L.ga.acc_y, dt);
@@ -210,7 +212,10 @@ __global__ void __launch_bounds__(256) sfw_costmap_scan_kernel(const sfw_launch 
   const int64_t local = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (local >= L.chunk_count) return;
   const int64_t t = L.chunk_begin + local;
-  if (L.status[t] == SFW_ST_SKIPPED) return;
+  if (L.status[t] == SFW_ST_SKIPPED) {
+    if (L.n_points) L.n_points[local] = 0;
+    return;
+  }
   const int S = L.S;
   double cm = 0.0;
   int n_ok = 0;
@@ -230,7 +235,7 @@ __global__ void __launch_bounds__(256) sfw_costmap_scan_kernel(const sfw_launch 
       }
     }
   }
-  if (L.n_points) *L.n_points = n_ok;
+  if (L.n_points) L.n_points[local] = n_ok;
   if (n_ok < S) {
     L.status[t] = SFW_ST_INVALID;
     L.costs[t] = SFW_COST_INVALID;
@@ -486,7 +491,7 @@ template <typename R> __device__ __forceinline__ sfm_consts<R> make_consts(const
 // (for the robot: its social force only).  Returns this slot's social work.
 template <typename R>
 __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_layout &s, const sfw_robot_step &rs,
-                                             int i, int g, int sl, int O, double inv_O, int robot_id,
+                                             int step, int i, int g, int sl, int O, double inv_O, int robot_id,
                                              double &px, double &py, double &vx, double &vy, double Fx, double Fy,
                                              double &nfx, double &nfy) {
   double work = 0.0;
@@ -528,7 +533,7 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_l
     }
     // dynamic collision with the robot's post-step pose (ref :613-627)
     const double cx = rs.x - px, cy = rs.y - py;
-    if (cx * cx + cy * cy <= k.rr) s.dead[g] = 2;
+    if (cx * cx + cy * cy <= k.rr) s.dead[g] = 2 + step;  // >= 2: rejected by contact at `step`
     // Wp (ref :692-699): force the post-step robot alone exerts on this person
     if (s.id[i] != robot_id) {
       R qx, qy;
@@ -589,7 +594,11 @@ __device__ __forceinline__ void finish_wave(const sfw_launch &L, const lds_layou
       const int64_t t = L.chunk_begin + first_local;
       const int d = s.dead[0];
       if (d == 0) L.costs[t] = L.base_cost[t] + L.p.social_weight * v;
-      else if (d == 2) { L.costs[t] = SFW_COST_INVALID; L.status[t] = SFW_ST_INVALID; }
+      else if (d >= 2) {
+        L.costs[t] = SFW_COST_INVALID;
+        L.status[t] = SFW_ST_INVALID;
+        if (L.coll_step) L.coll_step[t] = d - 2;
+      }
     }
   } else {
     // G > 1 (GA <= 64): per-slot sums were written to swp[]; every sample is reduced
@@ -603,7 +612,11 @@ __device__ __forceinline__ void finish_wave(const sfw_launch &L, const lds_layou
         const int64_t t = L.chunk_begin + first_local + g;
         const int d = s.dead[g];
         if (d == 0) L.costs[t] = L.base_cost[t] + L.p.social_weight * v;
-        else if (d == 2) { L.costs[t] = SFW_COST_INVALID; L.status[t] = SFW_ST_INVALID; }
+        else if (d >= 2) {
+          L.costs[t] = SFW_COST_INVALID;
+          L.status[t] = SFW_ST_INVALID;
+          if (L.coll_step) L.coll_step[t] = d - 2;
+        }
       }
     }
   }
@@ -728,7 +741,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         const sfw_robot_step rs = L.rstep[static_cast<int64_t>(step) * L.rstep_stride + first_local + g_[r]];
         const double2 Fj = s.frj[sl];
         double nfx, nfy;
-        sw[r] += agent_step<R>(k, s, rs, i_[r], g_[r], sl, O, inv_O, robot_id, px[r], py[r], vx[r], vy[r],
+        sw[r] += agent_step<R>(k, s, rs, step, i_[r], g_[r], sl, O, inv_O, robot_id, px[r], py[r], vx[r], vy[r],
                                fx[r] + Fj.x, fy[r] + Fj.y, nfx, nfy);
         fx[r] = nfx;
         fy[r] = nfy;
@@ -848,7 +861,7 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel_flat(const sfw_launch 
       const double2 Fi = s.frc[sl], Fj = s.frj[sl];
       double2 p = s.pos[sl], v = s.vel[sl];
       double nfx, nfy;
-      const double w = agent_step<R>(k, s, rs, sl, 0, sl, O, inv_O, robot_id, p.x, p.y, v.x, v.y, Fi.x + Fj.x,
+      const double w = agent_step<R>(k, s, rs, step, sl, 0, sl, O, inv_O, robot_id, p.x, p.y, v.x, v.y, Fi.x + Fj.x,
                                      Fi.y + Fj.y, nfx, nfy);
       s.swp[sl] += w;
       s.pos[sl] = p;

@@ -50,6 +50,8 @@ def lib():
         L.sfwh_last_costs.argtypes = [vp, vp, C.c_int64]
         L.sfwh_last_costs.restype = C.c_int64
         L.sfwh_trajectory_points.argtypes = [vp, C.c_int64, vp, C.c_int32]
+        L.sfwh_all_trajectories.argtypes = [vp, vp, C.c_int32, vp]
+        L.sfwh_all_trajectories.restype = C.c_int64
         L.sfwh_get_yaw.argtypes = [C.c_double] * 4
         L.sfwh_get_yaw.restype = C.c_double
         _lib = L
@@ -137,6 +139,14 @@ class HostPlanner:
         out = np.zeros(n, dtype=np.float64)
         lib().sfwh_last_costs(self._h, out.ctypes.data, n)
         return out
+
+    def all_trajectories(self, n_samples, cap):
+        pts = np.zeros((n_samples, cap, 3), dtype=np.float64)
+        counts = np.zeros(n_samples, dtype=np.int32)
+        n = lib().sfwh_all_trajectories(self._h, pts.ctypes.data, cap, counts.ctypes.data)
+        if n < 0:
+            raise RuntimeError("getTrajectories failed")
+        return pts[:n], counts[:n]
 
     def trajectory_points(self, index, cap=4096):
         pts = np.zeros((cap, 3), dtype=np.float64)

@@ -176,6 +176,19 @@ int sfwh_trajectory_points(void *hv, int64_t index, double *xyth, int32_t cap) {
     return n;
   });
 }
+// all trajectories of the last grid: xyth = T x cap x 3, counts = T; returns T or -1
+int64_t sfwh_all_trajectories(void *hv, double *xyth, int32_t cap, int32_t *counts) {
+  HostHandle *h = static_cast<HostHandle *>(hv);
+  std::vector<Trajectory> ts;
+  if (!h->planner->getTrajectories(ts)) return -1;
+  for (size_t i = 0; i < ts.size(); ++i) {
+    const int n = static_cast<int>(ts[i].getPointsSize());
+    counts[i] = n;
+    for (int k = 0; k < n && k < cap; ++k)
+      ts[i].getPoint(k, xyth[(i * cap + k) * 3], xyth[(i * cap + k) * 3 + 1], xyth[(i * cap + k) * 3 + 2]);
+  }
+  return static_cast<int64_t>(ts.size());
+}
 double sfwh_get_yaw(double x, double y, double z, double w) { return getYaw(Quaternion{x, y, z, w}); }
 }
 

@@ -303,6 +303,27 @@ bool SFWPlanner::getTrajectoryPoints(int64_t index, Trajectory &out) {
   return true;
 }
 
+bool SFWPlanner::getTrajectories(std::vector<Trajectory> &out) {
+  if (!grid_staged_) return false;
+  int S = static_cast<int>(params_.sim_time_ / params_.sim_granularity_ + 0.5);
+  if (S == 0) S = 1;
+  const int64_t nw = static_cast<int64_t>(angvels_.size());
+  const int64_t T = static_cast<int64_t>(linvels_.size()) * nw;
+  std::vector<double> pts(static_cast<size_t>(3) * S * T);
+  std::vector<int32_t> n(static_cast<size_t>(T));
+  if (sfw_grid_points_batch(handle_, 0, T, pts.data(), n.data()) != SFW_OK) return false;
+  out.assign(static_cast<size_t>(T), Trajectory());
+  for (int64_t i = 0; i < T; ++i) {
+    Trajectory &t = out[static_cast<size_t>(i)];
+    t.xv_ = linvels_[static_cast<size_t>(i / nw)];
+    t.thetav_ = angvels_[static_cast<size_t>(i % nw)];
+    t.cost_ = last_costs_[static_cast<size_t>(i)];
+    const double *p = pts.data() + static_cast<size_t>(i) * 3 * S;
+    for (int k = 0; k < n[static_cast<size_t>(i)]; ++k) t.addPoint(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+  }
+  return true;
+}
+
 bool SFWPlanner::updatePlan(const std::vector<PoseStamped> &new_plan) {  // ref :853-892
   goal_reached_ = false;
   global_plan_ = new_plan;

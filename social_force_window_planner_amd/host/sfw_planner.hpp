@@ -137,6 +137,10 @@ class SFWPlanner {
   enum Branch { kNotRunning = 0, kGoalReached, kRotateInPlace, kRotateBlocked, kApproach, kGrid, kGridFailed };
   // Trajectory points of sample `index` of the last grid (src/sfw_planner.cpp:366-374).
   bool getTrajectoryPoints(int64_t index, Trajectory &out);
+  // All samples of the last grid in one device call = what the reference's MarkerArray holds
+  // after the loop (:347-386): points of every scored sample, cost_ < 0 for rejected ones
+  // (drawn red there), the winner is lastBest().index (drawn green).
+  bool getTrajectories(std::vector<Trajectory> &out);
   int wpIndex() const { return wp_index_; }
   bool running() const { return running_; }
 

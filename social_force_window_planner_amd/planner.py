@@ -82,6 +82,7 @@ def lib():
         L.sfw_grid_fetch.argtypes = [vp, vp, C.POINTER(SfwBest), C.POINTER(SfwBestKey)]
         L.sfw_last_launch_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
         L.sfw_grid_points.argtypes = [vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32)]
+        L.sfw_grid_points_batch.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
         L.sfw_stream.argtypes = [vp]
         L.sfw_stream.restype = vp
         _lib = L
@@ -202,6 +203,14 @@ class HipScorer:
         ms = C.c_float()
         self._check(lib().sfw_last_launch_ms(self._h, which, C.byref(ms)), "sfw_last_launch_ms")
         return ms.value
+
+    def grid_points_batch(self, first, count, n_steps):
+        """Trajectory points of `count` consecutive samples: (points[count, n_steps, 3], n_points[count])."""
+        pts = np.zeros((count, n_steps, 3), dtype=np.float64)
+        n = np.zeros(count, dtype=np.int32)
+        self._check(lib().sfw_grid_points_batch(self._h, first, count, pts.ctypes.data, n.ctypes.data),
+                    "sfw_grid_points_batch")
+        return pts, n
 
     def grid_points(self, index, points_cap=4096):
         pts = np.zeros((points_cap, 3), dtype=np.float64)

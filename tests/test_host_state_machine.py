@@ -99,7 +99,7 @@ def test_grid_branch_matches_oracle_over_a_drive(oracle_mod, host_built):
         pl.update_plan(_plan())
     pose, vel = np.array([0.0, 0.0, 0.0]), np.array([0.3, 0.0, 0.0])
     for cycle in range(6):
-        used_pose = pose.copy()
+        used_pose, used_vel = pose.copy(), vel.copy()
         ro = o.find_best_action(pose, vel)
         rh = h.find_best_action(pose, vel)
         assert ro[2] == BRANCH_GRID
@@ -116,6 +116,15 @@ def test_grid_branch_matches_oracle_over_a_drive(oracle_mod, host_built):
     assert o.wp_index > 1
     pts = h.trajectory_points(int(np.flatnonzero(h.last_costs() >= 0)[0]))
     assert pts.shape == (40, 3) and np.allclose(pts[0], np.float32(used_pose), atol=1e-6)
+    # all 45 marker trajectories in one call (reference :347-386) == the oracle's per-sample points
+    allp, counts = h.all_trajectories(45, 40)
+    lin, ang = syn.reference_sampler()
+    rs = tuple(float(np.float32(v)) for v in (*used_pose, *used_vel))
+    wp = _plan()[o.wp_index]
+    assert counts[0] == 0  # the never-scored (0,0) sample has no points
+    for i in range(1, 45):
+        c, po = o.scorer.score_one(rs, lin[i // 9], 0.0, ang[i % 9], (1.0, 0.0, 1.0, wp[0], wp[1]))
+        assert counts[i] == len(po) and np.allclose(allp[i, :counts[i]], po, atol=1e-13)
 
 
 @pytest.mark.gpu
