@@ -85,6 +85,8 @@ struct sfw_planner_s {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> chunk_ev;  // 3 per chunk of a multi-chunk launch: K1 start, K1 end/K2 start, K2 end
+  int n_chunks = 1;
   std::string err;
 
   // world state
@@ -262,15 +264,25 @@ int launch_common(sfw_handle h) {
     return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
   SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
   const bool single = chunk >= T;
-  for (int64_t b = 0; b < T; b += chunk) {
+  h->n_chunks = static_cast<int>((T + chunk - 1) / chunk);
+  if (!single) {
+    while (h->chunk_ev.size() < static_cast<size_t>(3 * h->n_chunks)) {
+      hipEvent_t e = nullptr;
+      SFW_HIP(h, hipEventCreate(&e));
+      h->chunk_ev.push_back(e);
+    }
+  }
+  int c = 0;
+  for (int64_t b = 0; b < T; b += chunk, ++c) {
     const int64_t n = (T - b < chunk) ? (T - b) : chunk;
     sfw_launch L;
     fill_launch(h, L, b, n, chunk);
+    if (!single) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c], h->stream));
     SFW_HIP(h, sfw_launch_rollout(L, h->stream));
-    if (single) SFW_HIP(h, hipEventRecord(h->ev[1], h->stream));
+    SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
     SFW_HIP(h, sfw_launch_social(L, h->stream));
+    if (!single) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c + 2], h->stream));
   }
-  if (!single) SFW_HIP(h, hipEventRecord(h->ev[1], h->stream));  // K1/K2 interleaved: split not meaningful
   SFW_HIP(h, hipEventRecord(h->ev[2], h->stream));
   SFW_HIP(h, sfw_launch_argmin(h->costs.p, h->linvels.p, h->angvels.p, h->nw, T, h->index_base,
                                h->partials.p, h->sel.p, h->stream));
@@ -398,6 +410,8 @@ int sfw_destroy(sfw_handle h) {
   h->pin_grid.release();
   h->pin_out.release();
   for (auto &e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto &e : h->chunk_ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -601,6 +615,17 @@ int sfw_last_launch_ms(sfw_handle h, int32_t which, float *ms_out) {
   if (!h->launched) return fail(h, SFW_ERR_STATE, "last_launch_ms before grid_launch");
   SFW_HIP(h, hipSetDevice(h->device));
   SFW_HIP(h, hipEventSynchronize(h->ev[3]));
+  if (h->n_chunks > 1 && (which == 1 || which == 2)) {  // sum over the chunks of a multi-chunk launch
+    float total = 0.0f;
+    for (int c = 0; c < h->n_chunks; ++c) {
+      float ms = 0.0f;
+      const int a = 3 * c + (which == 1 ? 0 : 1);
+      SFW_HIP(h, hipEventElapsedTime(&ms, h->chunk_ev[a], h->chunk_ev[a + 1]));
+      total += ms;
+    }
+    *ms_out = total;
+    return SFW_OK;
+  }
   int a = 0, b = 3;
   switch (which) {
     case 0: a = 0; b = 3; break;

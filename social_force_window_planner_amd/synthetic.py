@@ -81,6 +81,7 @@ class Workload:
     n_obstacles: int = 0
     sampler: str = "generalised"  # "generalised" | "reference"
     n_discs: int = 10
+    people_r_in: float | None = None  # inner radius of the pedestrian annulus (None: see make_people)
 
     @property
     def n_samples(self):
@@ -164,12 +165,17 @@ def make_footprint(kind, radius=0.35):
 
 
 def make_people(n, rng, robot_xy=(0.0, 0.0), naive_goal_time=2.0, person_radius=0.35,
-                people_velocity=1.0):
+                people_velocity=1.0, r_in=None):
     """N pedestrians in an annulus 0.8..r_out m around the robot, >= 0.7 m apart
     (r_out = 5 m, widened for dense crowds so rejection sampling terminates),
     speed U(0.2,1.3), heading U(-pi,pi), goal = pos + naive_goal_time*vel
     (reference src/sensor_interface.cpp:494-503)."""
-    r_in = 0.8
+    # SURVEY.md §8d: annulus from 0.8 m.  Dense crowds (N >= 150, BASELINE cfg4) start from
+    # 2.1 m instead: closer than robot 0.7 m/s + pedestrian 1.0 m/s can close in the 1 s horizon
+    # plus the 0.35 m contact radius, every one of the ~1e6 samples is rejected by an early contact
+    # and the "LDS people-tiling stress" configuration would measure early exits, not the rollout.
+    if r_in is None:
+        r_in = 0.8 if n < 150 else 2.1
     r_out = max(5.0, math.sqrt(n * person_radius**2 / 0.35 + r_in**2))
     pts = []
     guard = 0
@@ -226,7 +232,7 @@ def make_scene(workload: Workload | str, max_vel_x=0.7, max_vel_th=0.5) -> Scene
     # src/sfw_planner.cpp:145-152)
     rs = (0.0, 0.0, 0.0, float(np.float32(0.3)), 0.0, 0.0)
     robot = make_robot_agent(rs[0], rs[1], rs[3], rs[4], max_vel_x=max_vel_x)
-    people = make_people(w.n_people, rng)
+    people = make_people(w.n_people, rng, r_in=w.people_r_in)
     arr = (SfwAgent * (1 + len(people)))(robot, *people)
     if w.n_obstacles > 0:
         a = np.arange(w.n_obstacles) * (2.0 * math.pi / w.n_obstacles)

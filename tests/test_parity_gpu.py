@@ -243,6 +243,15 @@ def test_dense_crowd_subgrid(oracle_mod, hip_mod):
     _assert_parity(oc, ob, gc, gb, RTOL_F64)
 
 
+def test_dense_crowd_contacts(oracle_mod, hip_mod):
+    """200 pedestrians from 0.8 m: most samples end in a pedestrian contact (-1) at some step;
+    the A > 128 kernel organisation must reject exactly the samples the oracle rejects."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg4"], nv=6, nw=6, people_r_in=0.8)
+    _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w, n_threads=36)
+    assert (oc == -1.0).sum() > 0
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
 # ---------------------------------------------------------------------------
 # Full BASELINE sizes: size-independent properties instead of the oracle
 # ---------------------------------------------------------------------------
