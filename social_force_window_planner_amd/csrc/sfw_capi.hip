@@ -99,6 +99,8 @@ struct sfw_planner_s {
   dev_buf<double> agent_pos, agent_vel, obstacles;
   dev_buf<sfw_agent_const> agent_c;
   dev_buf<int32_t> agent_grp, grp_off, grp_mem;
+  dev_buf<uint32_t> pair_tab;  // rebuilt when the agent count changes
+  int pair_tab_A = -1;
   int A = 0, O = 0, NG = 0, n_grp_mem = 0;
 
   // staged grid
@@ -191,6 +193,7 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.grp_mem = h->grp_mem.p;
   L.NG = h->NG;
   L.n_grp_mem = h->n_grp_mem;
+  L.pair_tab = h->pair_tab.p;
   L.status = h->status.p;
   L.base_cost = h->base_cost.p;
   L.costs = h->costs.p;
@@ -391,6 +394,7 @@ int sfw_destroy(sfw_handle h) {
   h->agent_grp.release();
   h->grp_off.release();
   h->grp_mem.release();
+  h->pair_tab.release();
   h->linvels.release();
   h->angvels.release();
   h->status.release();
@@ -533,6 +537,11 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   SFW_HIP(h, h2d(h->grp_off.p, o_off, 4 * off.size()));
   SFW_HIP(h, h2d(h->grp_mem.p, o_mem, 4 * mem.size()));
   SFW_HIP(h, h->pin_agents.mark(h->stream));
+  if (h->pair_tab_A != A) {
+    SFW_HIP(h, h->pair_tab.reserve(static_cast<size_t>(sfw_pair_table_entries(A))));
+    SFW_HIP(h, sfw_launch_pair_table(h->pair_tab.p, A, h->stream));
+    h->pair_tab_A = A;
+  }
   h->NG = static_cast<int>(ids.size());
   h->n_grp_mem = n_mem;
   h->A = A;

@@ -67,6 +67,8 @@ struct sfw_launch {
   const int32_t *grp_mem;          // grp_off[NG] member agent indices, ascending per group
   int32_t NG;
   int32_t n_grp_mem;
+  // flat social kernel: pair u -> packed LDS byte offsets (16*i | 16*j << 16), see sfw_launch_pair_table
+  const uint32_t *pair_tab;
   // per-sample outputs, indexed by GLOBAL sample index
   int32_t *status;       // T
   double *base_cost;     // T : vel + distance + angle + costmap terms (ref :663-666)
@@ -100,6 +102,9 @@ int64_t sfw_argmin_partials(int64_t T);
 hipError_t sfw_launch_argmin(const double *costs, const double *linvels, const double *angvels,
                              int32_t nw, int64_t T, int64_t index_base, sfw_sel *partials,
                              sfw_sel *out, hipStream_t stream);
+// Pair table of the flat social kernel for A agents: sfw_pair_table_entries(A) dwords.
+int64_t sfw_pair_table_entries(int A);
+hipError_t sfw_launch_pair_table(uint32_t *tab, int A, hipStream_t stream);
 // Samples handled by one wave of the social kernel for A agents.
 int sfw_samples_per_wave(int A, int64_t T);
 size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T);

@@ -317,7 +317,9 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   const R sn = fma(ix, uy, -(iy * ux));  // |I| sin(theta)
   const R cs = fma(ix, ux, iy * uy);     // |I| cos(theta)
   const R theta = atan2_abs(k.pc, fabs(sn), cs, il);  // |(sn,cs)| = |I| since dhat is unit
-  const R a = dn * rl * k.neg_inv_gamma;        // -|diff| / B
+  // -|diff| / B, clamped so that exp_fast's integer exponent stays in range for any input
+  // (exp(-800) is 0 in double and in float; the clamp never changes a result)
+  const R a = fmax(dn * rl * k.neg_inv_gamma, R(-800));
   const R bt2 = (k.gamma2 * l2) * (theta * theta);  // (B theta)^2, B^2 = gamma^2 |I|^2
   const R ev = exp_fast(k.pc, fma(-k.n_prime2, bt2, a));
   R ea = exp_fast(k.pc, fma(-k.n2, bt2, a));
@@ -327,7 +329,7 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   const R gx = ix * sc, gy = iy * sc;    // Fs * Ihat
   // f = -ev * (Fs Ihat) - ea * leftNormal(Fs Ihat),  leftNormal(x,y) = (-y, x)
   fx = fma(ea, gy, -(ev * gx));
-  fy = -fma(ev, gy, ea * gx);
+  fy = fma(-ev, gy, -(ea * gx));
 }
 template <typename R>
 __device__ __forceinline__ void pair_force_state(const sfm_consts<R> &k, double pix, double piy, double vix,
@@ -382,35 +384,60 @@ __device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const dou
   fy = static_cast<double>(ay) * inv_O;
 }
 
+// LDS map of one wave.  The four state arrays (pos, vel and the two force accumulators) come
+// first (pos, vel, frj, frc) and are `cap` records apart, so with a compile-time cap their distances fold into the
+// DS instructions' offset fields: one address VGPR per agent reaches all four.  The per-agent
+// launch constants are staged only when `consts` is set (the flat kernel without groups reads
+// them from global memory instead: 40 B/agent less LDS, which is what bounds its occupancy for
+// large crowds).  Built on the host with base = nullptr to size the allocation.
 struct lds_layout {
   double2 *pos, *vel, *frc, *frj, *goal, *obs, *gcen;
   double *gr, *dv, *rad, *swp;
   int *id, *hasgoal, *dead, *grp, *goff, *gmem;
-  __device__ lds_layout(char *base, int A, int GA, int G, int O, int NG, int NM) {
-    auto take = [&](size_t bytes) {
+  size_t bytes;
+  __host__ __device__ lds_layout(char *base, int A, int cap, int GA, int G, int O, int NG, int NM, bool consts,
+                                 bool with_frc) {
+    char *const base0 = base;
+    auto take = [&](size_t n) {
       char *p = base;
-      base += (bytes + 15) & ~size_t(15);
+      base += (n + 15) & ~size_t(15);
       return p;
     };
-    pos = reinterpret_cast<double2 *>(take(sizeof(double2) * GA));
-    vel = reinterpret_cast<double2 *>(take(sizeof(double2) * GA));
-    frc = reinterpret_cast<double2 *>(take(sizeof(double2) * GA));
-    frj = reinterpret_cast<double2 *>(take(sizeof(double2) * GA));
-    goal = reinterpret_cast<double2 *>(take(sizeof(double2) * A));
+    pos = reinterpret_cast<double2 *>(take(sizeof(double2) * cap));
+    vel = reinterpret_cast<double2 *>(take(sizeof(double2) * cap));
+    frj = reinterpret_cast<double2 *>(take(sizeof(double2) * cap));
+    frc = reinterpret_cast<double2 *>(take(sizeof(double2) * (with_frc ? cap : 0)));  // flat kernel only
     obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? O : 1)));
     swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
-    gr = reinterpret_cast<double *>(take(sizeof(double) * A));
-    dv = reinterpret_cast<double *>(take(sizeof(double) * A));
-    rad = reinterpret_cast<double *>(take(sizeof(double) * A));
-    id = reinterpret_cast<int *>(take(sizeof(int) * A));
     hasgoal = reinterpret_cast<int *>(take(sizeof(int) * GA));
     dead = reinterpret_cast<int *>(take(sizeof(int) * G));
+    const int Ac = consts ? A : 0;
+    goal = reinterpret_cast<double2 *>(take(sizeof(double2) * Ac));
+    gr = reinterpret_cast<double *>(take(sizeof(double) * Ac));
+    dv = reinterpret_cast<double *>(take(sizeof(double) * Ac));
+    rad = reinterpret_cast<double *>(take(sizeof(double) * Ac));
+    id = reinterpret_cast<int *>(take(sizeof(int) * Ac));
     gcen = reinterpret_cast<double2 *>(take(sizeof(double2) * (NG > 0 ? G * NG : 1)));
     grp = reinterpret_cast<int *>(take(sizeof(int) * (NG > 0 ? A : 1)));
     goff = reinterpret_cast<int *>(take(sizeof(int) * (NG + 1)));
     gmem = reinterpret_cast<int *>(take(sizeof(int) * (NM > 0 ? NM : 1)));
+    bytes = static_cast<size_t>(base - base0);
   }
 };
+
+// Per-agent launch constants as agent_step consumes them.
+struct agent_k {
+  double gx, gy, gr, dv, rad;
+  int id;
+};
+__device__ __forceinline__ agent_k agent_k_lds(const lds_layout &s, int i) {
+  const double2 g = s.goal[i];
+  return agent_k{g.x, g.y, s.gr[i], s.dv[i], s.rad[i], s.id[i]};
+}
+__device__ __forceinline__ agent_k agent_k_global(const sfw_launch &L, int i) {
+  const sfw_agent_const c = L.agent_c[i];
+  return agent_k{c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity, c.radius, c.id};
+}
 
 // lightsfm computeGroupForce (non-_PAPER_VERSION_ branch)
 // for agent i of sample g at position (px,py): gaze + coherence + repulsion.
@@ -491,16 +518,16 @@ template <typename R> __device__ __forceinline__ sfm_consts<R> make_consts(const
 // (for the robot: its social force only).  Returns this slot's social work.
 template <typename R>
 __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_layout &s, const sfw_robot_step &rs,
-                                             int step, int i, int g, int sl, int O, double inv_O, int robot_id,
-                                             double &px, double &py, double &vx, double &vy, double Fx, double Fy,
-                                             double &nfx, double &nfy) {
+                                             const agent_k &ak, int step, int i, int g, int sl, int O, double inv_O,
+                                             int robot_id, double &px, double &py, double &vx, double &vy, double Fx,
+                                             double Fy, double &nfx, double &nfy) {
   double work = 0.0;
   if (i == 0) {
     // Wr (ref :681-682): robot's social + obstacle force norms at the pre-step state
     work = fast_norm(Fx, Fy);
     if (O > 0) {
       double ox, oy;
-      obstacle_force<R>(k, s.obs, O, inv_O, px, py, s.rad[0], ox, oy);
+      obstacle_force<R>(k, s.obs, O, inv_O, px, py, ak.rad, ox, oy);
       work += fast_norm(ox, oy);
     }
     px = rs.x;   // ref :600
@@ -513,38 +540,35 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_l
     // lightsfm updatePosition, non-teleoperated branch
     vx = fma(Fx, k.dt, vx);
     vy = fma(Fy, k.dt, vy);
-    const double dv = s.dv[i];
     double rsp, sp;
     sfwm::rsqrt_sqrt(fmax(fma(vx, vx, vy * vy), 1e-300), rsp, sp);
-    if (sp > dv) {
-      const double sc = dv * rsp;  // normalize() then *= desiredVelocity
+    if (sp > ak.dv) {
+      const double sc = ak.dv * rsp;  // normalize() then *= desiredVelocity
       vx *= sc;
       vy *= sc;
     }
     px = fma(vx, k.dt, px);
     py = fma(vy, k.dt, py);
-    const double2 gl = s.goal[i];
-    const double grad = s.gr[i];
     int hg = s.hasgoal[sl];
     if (hg) {
-      const double ex = gl.x - px, ey = gl.y - py;
-      if (fast_norm(ex, ey) <= grad) hg = 0;  // goal reached: pop
+      const double ex = ak.gx - px, ey = ak.gy - py;
+      if (fast_norm(ex, ey) <= ak.gr) hg = 0;  // goal reached: pop
       s.hasgoal[sl] = hg;
     }
     // dynamic collision with the robot's post-step pose (ref :613-627)
     const double cx = rs.x - px, cy = rs.y - py;
     if (cx * cx + cy * cy <= k.rr) s.dead[g] = 2 + step;  // >= 2: rejected by contact at `step`
     // Wp (ref :692-699): force the post-step robot alone exerts on this person
-    if (s.id[i] != robot_id) {
+    if (ak.id != robot_id) {
       R qx, qy;
       pair_force_state<R>(k, px, py, vx, vy, rs.x, rs.y, rs.vx, rs.vy, qx, qy);
       work = fast_norm(static_cast<double>(qx), static_cast<double>(qy));
     }
     // desired + obstacle force at the new state = next step's starting force
-    desired_force<R>(k, px, py, vx, vy, hg != 0, gl.x, gl.y, grad, dv, nfx, nfy);
+    desired_force<R>(k, px, py, vx, vy, hg != 0, ak.gx, ak.gy, ak.gr, ak.dv, nfx, nfy);
     if (O > 0) {
       double ox, oy;
-      obstacle_force<R>(k, s.obs, O, inv_O, px, py, s.rad[i], ox, oy);
+      obstacle_force<R>(k, s.obs, O, inv_O, px, py, ak.rad, ox, oy);
       nfx += ox;
       nfy += oy;
     }
@@ -554,17 +578,19 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_l
 
 // Stage the per-launch constants and the initial agent state into LDS; returns
 // false when every sample of this wave was already rejected by K1.
-template <bool GROUPS>
+template <bool GROUPS, bool CONSTS>
 __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout &s, int lane, int G, int Gn,
                                            int64_t first_local) {
   const int A = L.A, O = L.O;
-  for (int i = lane; i < A; i += WAVE) {
-    const sfw_agent_const c = L.agent_c[i];
-    s.goal[i] = double2{c.goal_x, c.goal_y};
-    s.gr[i] = c.goal_radius;
-    s.dv[i] = c.desired_velocity;
-    s.rad[i] = c.radius;
-    s.id[i] = c.id;
+  if constexpr (CONSTS) {
+    for (int i = lane; i < A; i += WAVE) {
+      const sfw_agent_const c = L.agent_c[i];
+      s.goal[i] = double2{c.goal_x, c.goal_y};
+      s.gr[i] = c.goal_radius;
+      s.dv[i] = c.desired_velocity;
+      s.rad[i] = c.radius;
+      s.id[i] = c.id;
+    }
   }
   for (int o = lane; o < O; o += WAVE) s.obs[o] = double2{L.obstacles[2 * o], L.obstacles[2 * o + 1]};
   if constexpr (GROUPS) {
@@ -632,20 +658,26 @@ __device__ __forceinline__ void finish_wave(const sfw_launch &L, const lds_layou
 // the i-side force accumulates in registers, the j-side goes through one LDS
 // atomic whose addresses are all distinct within the instruction.
 // ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T &lds_at(char *base, int byte_off) {
+  return *reinterpret_cast<T *>(base + byte_off);
+}
+
 template <typename R, int NS, bool GROUPS>
 __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social_kernel(const sfw_launch L, const int G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CAP = WAVE * NS;             // GA <= CAP: state arrays at compile-time distances
+  constexpr int VEL = 16 * CAP, FRJ = 32 * CAP;  // byte offsets of vel[] / frj[] from pos[]
   const int lane = threadIdx.x;
   const int A = L.A, O = L.O, S = L.S;
   const int GA = G * A;
   const int NG = GROUPS ? L.NG : 0;  // GROUPS=false instantiation: no group code, lean register budget
-  const lds_layout s(smem, A, GA, G, O, NG, GROUPS ? L.n_grp_mem : 0);
+  const lds_layout s(smem, A, CAP, GA, G, O, NG, GROUPS ? L.n_grp_mem : 0, true, false);
   const int64_t first_local = static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x)) * G;
   const int64_t remain = L.chunk_count - first_local;
   const int Gn = remain < G ? static_cast<int>(remain) : G;
   const sfm_consts<R> k = make_consts<R>(L);
   const double inv_O = O > 0 ? 1.0 / O : 0.0;
-  if (!stage_wave<GROUPS>(L, s, lane, G, Gn, first_local)) return;
+  if (!stage_wave<GROUPS, true>(L, s, lane, G, Gn, first_local)) return;
 
   // ---- this lane's slots --------------------------------------------------
   int sl_[NS], g_[NS], i_[NS];
@@ -708,26 +740,34 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
 
   const int rows = A / 2;            // half ring; for even A the last row is half length
   const bool even = (A & 1) == 0;
-  const int robot_id = s.id[0];
+  const int robot_id = L.agent_c[0].id;
+  // byte offset (within pos[]) of the partner each slot meets next, and its wrap bound:
+  // the partner walks i+1, i+2, ... inside the slot's own sample
+  int jo_[NS], hi_[NS];
+#pragma unroll
+  for (int r = 0; r < NS; ++r) hi_[r] = 16 * (sl_[r] - i_[r] + A);
+  const int wrap = 16 * A;
 
   for (int step = 0; step < S; ++step) {
     // ---- pair pass: social forces at the pre-step state -------------------
+#pragma unroll
+    for (int r = 0; r < NS; ++r) jo_[r] = 16 * sl_[r];
     for (int row = 0; row < rows; ++row) {
       const bool half = even && (row == rows - 1);
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        const int i = i_[r];
-        if (ok_[r] && !(half && i >= rows)) {
-          int j = i + row + 1;
-          j = (j >= A) ? j - A : j;
-          const int sj = sl_[r] - i + j;
-          const double2 pj = s.pos[sj], vj = s.vel[sj];
+        int jo = jo_[r] + 16;
+        jo = (jo >= hi_[r]) ? jo - wrap : jo;
+        jo_[r] = jo;
+        if (ok_[r] && !(half && i_[r] >= rows)) {
+          const double2 pj = lds_at<double2>(smem, jo), vj = lds_at<double2>(smem, jo + VEL);
           R qx, qy;
           pair_force_state<R>(k, px[r], py[r], vx[r], vy[r], pj.x, pj.y, vj.x, vj.y, qx, qy);
           fx[r] += static_cast<double>(qx);
           fy[r] += static_cast<double>(qy);
-          atomicAdd(&s.frj[sj].x, -static_cast<double>(qx));
-          atomicAdd(&s.frj[sj].y, -static_cast<double>(qy));
+          // the partner receives -q: accumulated with the opposite sign, subtracted in the agent pass
+          atomicAdd(&lds_at<double>(smem, jo + FRJ), static_cast<double>(qx));
+          atomicAdd(&lds_at<double>(smem, jo + FRJ + 8), static_cast<double>(qy));
         }
       }
     }
@@ -741,8 +781,8 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         const sfw_robot_step rs = L.rstep[static_cast<int64_t>(step) * L.rstep_stride + first_local + g_[r]];
         const double2 Fj = s.frj[sl];
         double nfx, nfy;
-        sw[r] += agent_step<R>(k, s, rs, step, i_[r], g_[r], sl, O, inv_O, robot_id, px[r], py[r], vx[r], vy[r],
-                               fx[r] + Fj.x, fy[r] + Fj.y, nfx, nfy);
+        sw[r] += agent_step<R>(k, s, rs, agent_k_lds(s, i_[r]), step, i_[r], g_[r], sl, O, inv_O, robot_id, px[r],
+                               py[r], vx[r], vy[r], fx[r] - Fj.x, fy[r] - Fj.y, nfx, nfy);
         fx[r] = nfx;
         fy[r] = nfy;
         s.pos[sl] = double2{px[r], py[r]};
@@ -773,35 +813,60 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
 // 64*NS - A lanes).  All agent state lives in LDS; both sides of a pair go through
 // LDS atomics, into two accumulators per agent (received "as i" / "as j") so that
 // each accumulator's summation order is a function of u only.
+//
+// The u -> (i, j) map is the same for every step of every sample, so it is not
+// recomputed: sfw_pair_table_kernel writes it once per agent set as packed LDS
+// byte offsets (16*i | 16*j << 16, padded to a multiple of 64 with PAIR_NONE) and
+// the pair loop reads one coalesced dword per lane per iteration (L2-resident,
+// shared by all waves).  With the state arrays CAP records apart (CAP = 0: A,
+// run-time) the loop's integer work is two unpack instructions.
 // ---------------------------------------------------------------------------
-template <typename R, bool GROUPS>
+constexpr uint32_t PAIR_NONE = 0xFFFFFFFFu;
+
+__global__ void __launch_bounds__(256) sfw_pair_table_kernel(uint32_t *tab, int A, int n_entries) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_entries) return;
+  const int P = A * (A - 1) / 2;
+  uint32_t e = PAIR_NONE;
+  if (u < P) {
+    const int row = u / A, i = u - row * A;
+    int j = i + row + 1;
+    j = (j >= A) ? j - A : j;
+    e = static_cast<uint32_t>(16 * i) | (static_cast<uint32_t>(16 * j) << 16);
+  }
+  tab[u] = e;
+}
+
+template <typename R, bool GROUPS, int CAP>
 __global__ void __launch_bounds__(WAVE) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   (void)G_unused;
   const int lane = threadIdx.x;
   const int A = L.A, O = L.O, S = L.S;
   const int NG = GROUPS ? L.NG : 0;
-  const lds_layout s(smem, A, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0);
+  const int cap = CAP > 0 ? CAP : A;
+  const int VEL = 16 * cap, FRJ = 32 * cap, FRC = 48 * cap;  // byte offsets from pos[] (immediates when CAP > 0)
+  const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, GROUPS, true);
   const int64_t first_local = xcd_contiguous(blockIdx.x, gridDim.x);
   const sfm_consts<R> k = make_consts<R>(L);
   const double inv_O = O > 0 ? 1.0 / O : 0.0;
-  if (!stage_wave<GROUPS>(L, s, lane, 1, 1, first_local)) return;
+  if (!stage_wave<GROUPS, GROUPS>(L, s, lane, 1, 1, first_local)) return;
 
   for (int sl = lane; sl < A; sl += WAVE) {
     const double px = L.agent_pos[2 * sl], py = L.agent_pos[2 * sl + 1];
     const double vx = L.agent_vel[2 * sl], vy = L.agent_vel[2 * sl + 1];
-    const int hg = L.agent_c[sl].has_goal;
+    const sfw_agent_const c = L.agent_c[sl];
     s.pos[sl] = double2{px, py};
     s.vel[sl] = double2{vx, vy};
-    s.hasgoal[sl] = hg;
+    s.hasgoal[sl] = c.has_goal;
     s.swp[sl] = 0.0;
     double fx = 0.0, fy = 0.0;
     if (sl != 0) {
-      const double2 gl = s.goal[sl];
-      desired_force<R>(k, px, py, vx, vy, hg != 0, gl.x, gl.y, s.gr[sl], s.dv[sl], fx, fy);
+      desired_force<R>(k, px, py, vx, vy, c.has_goal != 0, c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity, fx,
+                       fy);
       if (O > 0) {
         double ox, oy;
-        obstacle_force<R>(k, s.obs, O, inv_O, px, py, s.rad[sl], ox, oy);
+        obstacle_force<R>(k, s.obs, O, inv_O, px, py, c.radius, ox, oy);
         fx += ox;
         fy += oy;
       }
@@ -834,35 +899,38 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel_flat(const sfw_launch 
   if constexpr (GROUPS) add_group_forces();
 
   const int P = A * (A - 1) / 2;  // unordered pairs
-  const int robot_id = s.id[0];
-  // this lane's first item and the per-iteration stride 64 = dq*A + dr
-  const int dq = WAVE / A, dr = WAVE - dq * A;
-  const int row0 = lane / A, i0 = lane - row0 * A;
+  const int n_it = (P + WAVE - 1) / WAVE;
+  const int robot_id = L.agent_c[0].id;
 
   for (int step = 0; step < S; ++step) {
-    int row = row0, i = i0;
-    for (int u = lane; u < P; u += WAVE) {
-      int j = i + row + 1;
-      j = (j >= A) ? j - A : j;
-      const double2 pi = s.pos[i], pj = s.pos[j], vi = s.vel[i], vj = s.vel[j];
-      R qx, qy;
-      pair_force_state<R>(k, pi.x, pi.y, vi.x, vi.y, pj.x, pj.y, vj.x, vj.y, qx, qy);
-      atomicAdd(&s.frc[i].x, static_cast<double>(qx));
-      atomicAdd(&s.frc[i].y, static_cast<double>(qy));
-      atomicAdd(&s.frj[j].x, -static_cast<double>(qx));
-      atomicAdd(&s.frj[j].y, -static_cast<double>(qy));
-      i += dr;
-      row += dq;
-      if (i >= A) { i -= A; ++row; }
+    const uint32_t *row = L.pair_tab;  // wave-uniform: scalar base + constant lane offset
+    uint32_t next = n_it > 0 ? row[lane] : PAIR_NONE;
+    for (int it = 0; it < n_it; ++it) {
+      const uint32_t e = next;
+      row += WAVE;
+      if (it + 1 < n_it) next = row[lane];  // in flight during this pair's arithmetic
+      if (e != PAIR_NONE) {
+        const int io = static_cast<int>(e & 0xFFFFu), jo = static_cast<int>(e >> 16);
+        const double2 pi = lds_at<double2>(smem, io), vi = lds_at<double2>(smem, io + VEL);
+        const double2 pj = lds_at<double2>(smem, jo), vj = lds_at<double2>(smem, jo + VEL);
+        R qx, qy;
+        pair_force_state<R>(k, pi.x, pi.y, vi.x, vi.y, pj.x, pj.y, vj.x, vj.y, qx, qy);
+        atomicAdd(&lds_at<double>(smem, io + FRC), static_cast<double>(qx));
+        atomicAdd(&lds_at<double>(smem, io + FRC + 8), static_cast<double>(qy));
+        // j receives -q: accumulated with the opposite sign, subtracted in the agent pass
+        atomicAdd(&lds_at<double>(smem, jo + FRJ), static_cast<double>(qx));
+        atomicAdd(&lds_at<double>(smem, jo + FRJ + 8), static_cast<double>(qy));
+      }
     }
     __syncthreads();
     const sfw_robot_step rs = L.rstep[static_cast<int64_t>(step) * L.rstep_stride + first_local];
     for (int sl = lane; sl < A; sl += WAVE) {
+      const agent_k ak = GROUPS ? agent_k_lds(s, sl) : agent_k_global(L, sl);
       const double2 Fi = s.frc[sl], Fj = s.frj[sl];
       double2 p = s.pos[sl], v = s.vel[sl];
       double nfx, nfy;
-      const double w = agent_step<R>(k, s, rs, step, sl, 0, sl, O, inv_O, robot_id, p.x, p.y, v.x, v.y, Fi.x + Fj.x,
-                                     Fi.y + Fj.y, nfx, nfy);
+      const double w = agent_step<R>(k, s, rs, ak, step, sl, 0, sl, O, inv_O, robot_id, p.x, p.y, v.x, v.y,
+                                     Fi.x - Fj.x, Fi.y - Fj.y, nfx, nfy);
       s.swp[sl] += w;
       s.pos[sl] = p;
       s.vel[sl] = v;
@@ -1002,20 +1070,27 @@ static wave_plan plan_for(int A, int64_t T) {
 
 int sfw_samples_per_wave(int A, int64_t T) { return plan_for(A, T).G; }
 
+static int flat_cap(int A) { return A <= 64 ? 64 : A <= 128 ? 128 : A <= 256 ? 256 : 0; }
+
 size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T) {
-  const int G = sfw_samples_per_wave(A, T);
-  const size_t GA = static_cast<size_t>(G) * A;
-  auto up = [](size_t b) { return (b + 15) & ~size_t(15); };
-  size_t n = 0;
-  n += 4 * up(16 * GA);                     // pos, vel, frc, frj
-  n += up(16 * A);                          // goal
-  n += up(16 * (O > 0 ? O : 1));            // obs
-  n += up(8 * GA);                          // swp
-  n += 3 * up(8 * A);                       // gr, dv, rad
-  n += up(4 * A) + up(4 * GA) + up(4 * G);  // id, hasgoal, dead
-  n += up(16 * (NG > 0 ? static_cast<size_t>(G) * NG : 1)) + up(4 * (NG > 0 ? A : 1)) + up(4 * (NG + 1)) +
-       up(4 * (n_grp_mem > 0 ? n_grp_mem : 1));  // gcen, grp, goff, gmem
-  return n;
+  const wave_plan pl = plan_for(A, T);
+  if (pl.flat) {
+    const int c = flat_cap(A);
+    return lds_layout(nullptr, A, c > 0 ? c : A, A, 1, O, NG, n_grp_mem, NG > 0, true).bytes;
+  }
+  return lds_layout(nullptr, A, WAVE * pl.ns, pl.G * A, pl.G, O, NG, n_grp_mem, true, false).bytes;
+}
+
+int64_t sfw_pair_table_entries(int A) {
+  const int64_t P = static_cast<int64_t>(A) * (A - 1) / 2;
+  const int64_t n = (P + WAVE - 1) / WAVE * WAVE;
+  return n > 0 ? n : WAVE;
+}
+
+hipError_t sfw_launch_pair_table(uint32_t *tab, int A, hipStream_t stream) {
+  const int n = static_cast<int>(sfw_pair_table_entries(A));
+  hipLaunchKernelGGL(sfw_pair_table_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tab, A, n);
+  return hipGetLastError();
 }
 
 hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream) {
@@ -1055,12 +1130,28 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L,
   const unsigned grid = static_cast<unsigned>((L.chunk_count + pl.G - 1) / pl.G);
   const size_t lds = sfw_social_lds_bytes(L.A, L.O, L.NG, L.n_grp_mem, L.chunk_count);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  if (L.NG > 0) {  // at least one agent carries a group id: kernels with the group pass
-    if (pl.flat) return launch_social_as(sfw_social_kernel_flat<R, true>, L, 1, grid, lds, stream);
+  const bool groups = L.NG > 0;  // at least one agent carries a group id: kernels with the group pass
+  if (pl.flat) {
+    if (16 * static_cast<int64_t>(L.A) > 65535 || !L.pair_tab) return hipErrorInvalidValue;  // 16-bit packed offsets
+    switch (flat_cap(L.A)) {
+      case 64:
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 64>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 64>, L, 1, grid, lds, stream);
+      case 128:
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 128>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 128>, L, 1, grid, lds, stream);
+      case 256:
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 256>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 256>, L, 1, grid, lds, stream);
+      default:
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 0>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 0>, L, 1, grid, lds, stream);
+    }
+  }
+  if (groups) {
     if (pl.ns == 1) return launch_social_as(sfw_social_kernel<R, 1, true>, L, pl.G, grid, lds, stream);
     return launch_social_as(sfw_social_kernel<R, 2, true>, L, pl.G, grid, lds, stream);
   }
-  if (pl.flat) return launch_social_as(sfw_social_kernel_flat<R, false>, L, 1, grid, lds, stream);
   if (pl.ns == 1) return launch_social_as(sfw_social_kernel<R, 1, false>, L, pl.G, grid, lds, stream);
   return launch_social_as(sfw_social_kernel<R, 2, false>, L, pl.G, grid, lds, stream);
 }

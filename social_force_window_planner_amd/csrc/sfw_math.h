@@ -57,16 +57,21 @@ __device__ __forceinline__ double rcp_nr(double x) {
   const double e = fma(-x, y, 1.0);
   return fma(e, y, y);                // one Newton step: ~2^-46
 }
-// exp(x) for x < ~700 (the pair term has x <= 0, the obstacle term x <= radius/sigma):
-// no overflow handling; underflows to 0 through ldexp.
+// exp(x) for -1e9 < x < ~700 (the pair term has x <= 0 and is clamped by its caller, the
+// obstacle term x <= radius/sigma): no overflow handling; underflows to 0 through ldexp.
+// Round-to-nearest of x*log2(e) by the 1.5*2^52 shift: the shifted sum holds k in its low
+// mantissa bits (two's complement in the low dword), so no rint and no f64->i32 convert.  One
+// fma reduction step: the error of fl(ln2) reaches r as |k|*2.3e-17 (< 1e-14 relative up to
+// |k| ~ 400, where the result is ~1e-120 and far below anything it is added to).
 __device__ __forceinline__ double exp_fast(const poly_consts &pc, double x) {
-  const double k = __builtin_rint(x * 1.4426950408889634074);
-  double r = fma(k, -6.93147180369123816490e-01, x);
-  r = fma(k, -1.90821492927058770002e-10, r);
+  const double shift = 6755399441055744.0;  // 1.5 * 2^52
+  const double t = fma(x, 1.4426950408889634074, shift);
+  const double k = t - shift;
+  const double r = fma(k, -6.93147180559945286227e-01, x);
   double p = pc.ex[9];
 #pragma unroll
   for (int n = 8; n >= 0; --n) p = fma(p, r, pc.ex[n]);
-  return __builtin_amdgcn_ldexp(p, static_cast<int>(k));  // v_cvt_i32_f64 saturates, ldexp flushes to 0
+  return __builtin_amdgcn_ldexp(p, __double2loint(t));
 }
 // |atan2(y, x)| for y >= 0, result in [0, pi]; hyp = sqrt(x*x + y*y) > 0 (the
 // caller has it already).  Octant fold to phi in [0, pi/4], then the half-angle
