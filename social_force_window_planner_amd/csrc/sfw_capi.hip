@@ -193,6 +193,7 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.grp_mem = h->grp_mem.p;
   L.NG = h->NG;
   L.n_grp_mem = h->n_grp_mem;
+  sfw_derive(L);
   L.pair_tab = h->pair_tab.p;
   L.status = h->status.p;
   L.base_cost = h->base_cost.p;

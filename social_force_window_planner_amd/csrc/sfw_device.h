@@ -31,10 +31,24 @@ struct __attribute__((aligned(16))) sfw_agent_const {
   int32_t id, has_goal;
 };
 
+// Social-force constants derived from sfw_params on the host (sfw_derive), in the type the
+// forces are evaluated in.  They reach the kernels as kernel arguments, i.e. in SGPRs: a value
+// derived on the device (a division, a product) is a VALU result and would sit in a VGPR pair
+// of every lane for the whole rollout.
+template <typename R> struct sfw_force_k {
+  R lambda, gamma2, neg_inv_gamma, neg_n2, neg_n_prime2, f_social, f_obstacle, inv_sigma;
+};
+struct sfw_derived {
+  sfw_force_k<double> d;
+  sfw_force_k<float> f;
+  double f_desired, inv_tau, rr, inv_O;
+};
+
 // Everything the kernels need that is uniform over a launch.
 struct sfw_launch {
   // scoring parameters
   sfw_params p;
+  sfw_derived k;    // filled by sfw_derive
   int32_t S;        // num_steps
   double dt;        // sim_time / S
   // robot + goal
@@ -92,6 +106,9 @@ struct sfw_sel {
   long long neg_index;  // -(global iteration index)
   long long n_valid;
 };
+
+// Fills L.k from L.p and L.O (host).
+void sfw_derive(sfw_launch &L);
 
 // Launchers (sfw_kernels.hip).  All enqueue on `stream` and return hipError_t.
 hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream);

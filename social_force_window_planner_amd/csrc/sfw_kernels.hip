@@ -276,10 +276,10 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned n) {
   return x * q + (x < r ? x : r) + k;
 }
 
-// Per-launch social-force constants in the force type.
+// Per-launch social-force constants in the force type (host-derived, see sfw_derived).
 template <typename R> struct sfm_consts {
   sfwm::poly_consts pc;
-  R lambda, gamma2, neg_inv_gamma, n2, n_prime2, f_social;
+  R lambda, gamma2, neg_inv_gamma, neg_n2, neg_n_prime2, f_social;
   R f_obstacle, inv_sigma;
   double f_desired, inv_tau, dt, rr;
   double f_gaze, f_coherence, f_repulsion;
@@ -321,8 +321,8 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   // (exp(-800) is 0 in double and in float; the clamp never changes a result)
   const R a = fmax(dn * rl * k.neg_inv_gamma, R(-800));
   const R bt2 = (k.gamma2 * l2) * (theta * theta);  // (B theta)^2, B^2 = gamma^2 |I|^2
-  const R ev = exp_fast(k.pc, fma(-k.n_prime2, bt2, a));
-  R ea = exp_fast(k.pc, fma(-k.n2, bt2, a));
+  const R ev = exp_fast(k.pc, fma(k.neg_n_prime2, bt2, a));
+  R ea = exp_fast(k.pc, fma(k.neg_n2, bt2, a));
   // sign(theta) * exp(...): sign bit copied from cw, exact zero kept (relative rest)
   ea = (cw != 0.0) ? copysign_from(ea, cw) : R(0);
   const R sc = rl * k.f_social;
@@ -392,6 +392,7 @@ __device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const dou
 // large crowds).  Built on the host with base = nullptr to size the allocation.
 struct lds_layout {
   double2 *pos, *vel, *frc, *frj, *goal, *obs, *gcen;
+  sfw_robot_step *rsb;  // this step's robot record of each of the wave's samples (register form)
   double *gr, *dv, *rad, *swp;
   int *id, *hasgoal, *dead, *grp, *goff, *gmem;
   size_t bytes;
@@ -408,6 +409,7 @@ struct lds_layout {
     frj = reinterpret_cast<double2 *>(take(sizeof(double2) * cap));
     frc = reinterpret_cast<double2 *>(take(sizeof(double2) * (with_frc ? cap : 0)));  // flat kernel only
     obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? O : 1)));
+    rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * G));
     swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
     hasgoal = reinterpret_cast<int *>(take(sizeof(int) * GA));
     dead = reinterpret_cast<int *>(take(sizeof(int) * G));
@@ -492,20 +494,30 @@ __device__ double2 group_force(const sfm_consts<R> &k, const lds_layout &s, int 
   return double2{fx, fy};
 }
 
-template <typename R> __device__ __forceinline__ sfm_consts<R> make_consts(const sfw_launch &L) {
+template <typename R> __device__ __forceinline__ const sfw_force_k<R> &force_k(const sfw_launch &L);
+template <> __device__ __forceinline__ const sfw_force_k<double> &force_k<double>(const sfw_launch &L) { return L.k.d; }
+template <> __device__ __forceinline__ const sfw_force_k<float> &force_k<float>(const sfw_launch &L) { return L.k.f; }
+
+template <typename R, bool PIN_ALL> __device__ __forceinline__ sfm_consts<R> make_consts(const sfw_launch &L) {
+  const sfw_force_k<R> &f = force_k<R>(L);
   sfm_consts<R> k;
-  k.lambda = R(L.p.sfm_lambda);
-  k.gamma2 = R(L.p.sfm_gamma * L.p.sfm_gamma);
-  k.neg_inv_gamma = R(-1.0 / L.p.sfm_gamma);
-  k.n2 = R(L.p.sfm_n * L.p.sfm_n);
-  k.n_prime2 = R(L.p.sfm_n_prime * L.p.sfm_n_prime);
-  k.f_social = R(L.p.sfm_force_factor_social);
-  k.f_obstacle = R(L.p.sfm_force_factor_obstacle);
-  k.inv_sigma = R(1.0 / L.p.sfm_force_sigma_obstacle);
-  k.f_desired = L.p.sfm_force_factor_desired;
-  k.inv_tau = 1.0 / L.p.sfm_relaxation_time;
+  // The pair loop reads 33 distinct FP64 constants (19 polynomial coefficients, the range-reduction
+  // and fold constants, these six): 66 SGPRs, more than the allocator has left next to the
+  // kernel arguments, and it then reloads spilled ones with v_readlane inside the loop.  The VGPR
+  // file has the room, so these stay in vector registers (all six in the flat kernel, four in
+  // the register-resident one, which has to stay within 80 VGPRs for six waves per SIMD).
+  k.lambda = sfwm::vgpr_const(f.lambda);
+  k.gamma2 = sfwm::vgpr_const(f.gamma2);
+  k.neg_inv_gamma = sfwm::vgpr_const(f.neg_inv_gamma);
+  k.neg_n2 = PIN_ALL ? sfwm::vgpr_const(f.neg_n2) : f.neg_n2;
+  k.neg_n_prime2 = sfwm::vgpr_const(f.neg_n_prime2);
+  k.f_social = PIN_ALL ? sfwm::vgpr_const(f.f_social) : f.f_social;
+  k.f_obstacle = f.f_obstacle;
+  k.inv_sigma = f.inv_sigma;
+  k.f_desired = L.k.f_desired;
+  k.inv_tau = L.k.inv_tau;
   k.dt = L.dt;
-  k.rr = static_cast<double>(L.p.robot_radius * L.p.robot_radius);  // float product, ref :617
+  k.rr = L.k.rr;
   k.f_gaze = L.p.sfm_force_factor_group_gaze;
   k.f_coherence = L.p.sfm_force_factor_group_coherence;
   k.f_repulsion = L.p.sfm_force_factor_group_repulsion;
@@ -675,16 +687,21 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   const int64_t first_local = static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x)) * G;
   const int64_t remain = L.chunk_count - first_local;
   const int Gn = remain < G ? static_cast<int>(remain) : G;
-  const sfm_consts<R> k = make_consts<R>(L);
-  const double inv_O = O > 0 ? 1.0 / O : 0.0;
+  const sfm_consts<R> k = make_consts<R, false>(L);
+  const double inv_O = L.k.inv_O;
   if (!stage_wave<GROUPS, true>(L, s, lane, G, Gn, first_local)) return;
 
   // ---- this lane's slots --------------------------------------------------
   int sl_[NS], g_[NS], i_[NS];
   bool ok_[NS];
-  double px[NS], py[NS], vx[NS], vy[NS], fx[NS], fy[NS], sw[NS];
+  // Registers hold only the force accumulator and the social-work sum of a slot; position and
+  // velocity are re-read from LDS where needed (two more ds_read_b128 per pair, LDS has the
+  // headroom): with them in VGPRs the NS = 1 kernel needs 87 registers, i.e. scratch spills
+  // under the 80 that six waves per SIMD allow.
+  double fx[NS], fy[NS], sw[NS];
 #pragma unroll
   for (int r = 0; r < NS; ++r) {
+    double px[NS], py[NS], vx[NS], vy[NS];
     const int sl = r * WAVE + lane;
     ok_[r] = sl < GA;
     const int slc = ok_[r] ? sl : 0;
@@ -724,14 +741,16 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
 #pragma unroll
     for (int r = 0; r < NS; ++r)
       if (ok_[r] && s.grp[i_[r]] >= 0) {
-        atomicAdd(&s.gcen[g_[r] * NG + s.grp[i_[r]]].x, px[r]);
-        atomicAdd(&s.gcen[g_[r] * NG + s.grp[i_[r]]].y, py[r]);
+        const double2 p = s.pos[sl_[r]];
+        atomicAdd(&s.gcen[g_[r] * NG + s.grp[i_[r]]].x, p.x);
+        atomicAdd(&s.gcen[g_[r] * NG + s.grp[i_[r]]].y, p.y);
       }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NS; ++r)
       if (ok_[r] && i_[r] != 0) {
-        const double2 gf = group_force<R>(k, s, NG, g_[r], A, i_[r], sl_[r], px[r], py[r]);
+        const double2 p = s.pos[sl_[r]];
+        const double2 gf = group_force<R>(k, s, NG, g_[r], A, i_[r], sl_[r], p.x, p.y);
         fx[r] += gf.x;
         fy[r] += gf.y;
       }
@@ -749,6 +768,20 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   const int wrap = 16 * A;
 
   for (int step = 0; step < S; ++step) {
+    // This step's robot records (32 B per sample, contiguous) go from the K1 table straight to
+    // LDS (global_load_lds_dwordx4: no VGPRs), in flight during the pair pass.  The waves of a
+    // launch start together and run the same instruction stream, so a load issued where it is
+    // consumed stalls every resident wave of the SIMD at once (14 % of wave time in s_waitcnt
+    // at cfg2 before this, profiles/r01e).
+    for (int c = 0; c < 2 * Gn; c += WAVE)  // 16 B per lane, 64 lanes per instruction
+      if (c + lane < 2 * Gn) {
+        const char *src =
+            reinterpret_cast<const char *>(L.rstep + static_cast<int64_t>(step) * L.rstep_stride + first_local) +
+            16 * (c + lane);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(s.rsb) + 16 * c),
+                                         16, 0, 0);
+      }
     // ---- pair pass: social forces at the pre-step state -------------------
 #pragma unroll
     for (int r = 0; r < NS; ++r) jo_[r] = 16 * sl_[r];
@@ -760,9 +793,11 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         jo = (jo >= hi_[r]) ? jo - wrap : jo;
         jo_[r] = jo;
         if (ok_[r] && !(half && i_[r] >= rows)) {
+          const int io = 16 * sl_[r];
+          const double2 pi = lds_at<double2>(smem, io), vi = lds_at<double2>(smem, io + VEL);
           const double2 pj = lds_at<double2>(smem, jo), vj = lds_at<double2>(smem, jo + VEL);
           R qx, qy;
-          pair_force_state<R>(k, px[r], py[r], vx[r], vy[r], pj.x, pj.y, vj.x, vj.y, qx, qy);
+          pair_force_state<R>(k, pi.x, pi.y, vi.x, vi.y, pj.x, pj.y, vj.x, vj.y, qx, qy);
           fx[r] += static_cast<double>(qx);
           fy[r] += static_cast<double>(qy);
           // the partner receives -q: accumulated with the opposite sign, subtracted in the agent pass
@@ -771,6 +806,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         }
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct load above has landed
     __syncthreads();
 
     // ---- per-agent pass ---------------------------------------------------
@@ -778,15 +814,16 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     for (int r = 0; r < NS; ++r) {
       if (ok_[r] && s.dead[g_[r]] == 0) {
         const int sl = sl_[r];
-        const sfw_robot_step rs = L.rstep[static_cast<int64_t>(step) * L.rstep_stride + first_local + g_[r]];
+        const sfw_robot_step rs = s.rsb[g_[r]];
         const double2 Fj = s.frj[sl];
+        double2 p = s.pos[sl], v = s.vel[sl];
         double nfx, nfy;
-        sw[r] += agent_step<R>(k, s, rs, agent_k_lds(s, i_[r]), step, i_[r], g_[r], sl, O, inv_O, robot_id, px[r],
-                               py[r], vx[r], vy[r], fx[r] - Fj.x, fy[r] - Fj.y, nfx, nfy);
+        sw[r] += agent_step<R>(k, s, rs, agent_k_lds(s, i_[r]), step, i_[r], g_[r], sl, O, inv_O, robot_id, p.x, p.y,
+                               v.x, v.y, fx[r] - Fj.x, fy[r] - Fj.y, nfx, nfy);
         fx[r] = nfx;
         fy[r] = nfy;
-        s.pos[sl] = double2{px[r], py[r]};
-        s.vel[sl] = double2{vx[r], vy[r]};
+        s.pos[sl] = p;
+        s.vel[sl] = v;
         s.frj[sl] = double2{0.0, 0.0};
       }
     }
@@ -848,8 +885,8 @@ __global__ void __launch_bounds__(WAVE) sfw_social_kernel_flat(const sfw_launch 
   const int VEL = 16 * cap, FRJ = 32 * cap, FRC = 48 * cap;  // byte offsets from pos[] (immediates when CAP > 0)
   const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, GROUPS, true);
   const int64_t first_local = xcd_contiguous(blockIdx.x, gridDim.x);
-  const sfm_consts<R> k = make_consts<R>(L);
-  const double inv_O = O > 0 ? 1.0 / O : 0.0;
+  const sfm_consts<R> k = make_consts<R, true>(L);
+  const double inv_O = L.k.inv_O;
   if (!stage_wave<GROUPS, GROUPS>(L, s, lane, 1, 1, first_local)) return;
 
   for (int sl = lane; sl < A; sl += WAVE) {
@@ -1069,6 +1106,32 @@ static wave_plan plan_for(int A, int64_t T) {
 }
 
 int sfw_samples_per_wave(int A, int64_t T) { return plan_for(A, T).G; }
+
+void sfw_derive(sfw_launch &L) {
+  const sfw_params &p = L.p;
+  sfw_force_k<double> &d = L.k.d;
+  d.lambda = p.sfm_lambda;
+  d.gamma2 = p.sfm_gamma * p.sfm_gamma;
+  d.neg_inv_gamma = -1.0 / p.sfm_gamma;
+  d.neg_n2 = -(p.sfm_n * p.sfm_n);
+  d.neg_n_prime2 = -(p.sfm_n_prime * p.sfm_n_prime);
+  d.f_social = p.sfm_force_factor_social;
+  d.f_obstacle = p.sfm_force_factor_obstacle;
+  d.inv_sigma = 1.0 / p.sfm_force_sigma_obstacle;
+  sfw_force_k<float> &f = L.k.f;
+  f.lambda = static_cast<float>(d.lambda);
+  f.gamma2 = static_cast<float>(d.gamma2);
+  f.neg_inv_gamma = static_cast<float>(d.neg_inv_gamma);
+  f.neg_n2 = static_cast<float>(d.neg_n2);
+  f.neg_n_prime2 = static_cast<float>(d.neg_n_prime2);
+  f.f_social = static_cast<float>(d.f_social);
+  f.f_obstacle = static_cast<float>(d.f_obstacle);
+  f.inv_sigma = static_cast<float>(d.inv_sigma);
+  L.k.f_desired = p.sfm_force_factor_desired;
+  L.k.inv_tau = 1.0 / p.sfm_relaxation_time;
+  L.k.rr = static_cast<double>(static_cast<float>(p.robot_radius) * static_cast<float>(p.robot_radius));  // ref :617
+  L.k.inv_O = L.O > 0 ? 1.0 / L.O : 0.0;
+}
 
 static int flat_cap(int A) { return A <= 64 ? 64 : A <= 128 ? 128 : A <= 256 ? 256 : 0; }
 

@@ -34,6 +34,15 @@ __device__ __forceinline__ double sgpr_const(double c) {
   asm("" : "+s"(c));
   return c;
 }
+// The opposite pin: keep a wave-uniform value in a VGPR (see make_consts).
+__device__ __forceinline__ double vgpr_const(double c) {
+  asm("" : "+v"(c));
+  return c;
+}
+__device__ __forceinline__ float vgpr_const(float c) {
+  asm("" : "+v"(c));
+  return c;
+}
 struct poly_consts {
   double at[9], ex[10];
   __device__ __forceinline__ poly_consts() {

@@ -243,6 +243,16 @@ def test_dense_crowd_subgrid(oracle_mod, hip_mod):
     _assert_parity(oc, ob, gc, gb, RTOL_F64)
 
 
+@pytest.mark.parametrize("n_people", [300, 600])
+def test_very_dense_crowd_runtime_stride(oracle_mod, hip_mod, n_people):
+    """More than 256 agents: the flat kernel instantiation whose LDS state arrays are a run-time
+    number of records apart (CAP = 0), pair table beyond 2^15 entries."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg4"], nv=3, nw=4, n_people=n_people, sim_time=0.25, seed=40 + n_people)
+    _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w, n_threads=12)
+    assert (oc >= 0).sum() > 0
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
 def test_dense_crowd_contacts(oracle_mod, hip_mod):
     """200 pedestrians from 0.8 m: most samples end in a pedestrian contact (-1) at some step;
     the A > 128 kernel organisation must reject exactly the samples the oracle rejects."""

@@ -32,6 +32,16 @@ def _case(seed):
         robot_radius=float(rng.uniform(0.2, 0.5)), social_weight=float(rng.uniform(0.1, 3)),
         costmap_weight=float(rng.uniform(0, 3)), angle_weight=float(rng.uniform(0, 2)),
         distance_weight=float(rng.uniform(0.1, 2)), vel_weight=float(rng.uniform(0, 2)))
+    if seed % 3 == 0:  # non-default lightsfm parameters (the ABI carries them; the reference keeps the defaults)
+        p.sfm_lambda = float(rng.uniform(0.5, 3.0))
+        p.sfm_gamma = float(rng.uniform(0.2, 0.8))
+        p.sfm_n = float(rng.uniform(1.0, 3.5))
+        p.sfm_n_prime = float(rng.uniform(1.0, 3.5))
+        p.sfm_force_factor_social = float(rng.uniform(0.5, 4.0))
+        p.sfm_force_factor_desired = float(rng.uniform(0.5, 2.0))
+        p.sfm_force_factor_obstacle = float(rng.uniform(1.0, 20.0))
+        p.sfm_force_sigma_obstacle = float(rng.uniform(0.1, 0.5))
+        p.sfm_relaxation_time = float(rng.uniform(0.3, 1.0))
     rs = tuple(float(np.float32(v)) for v in (rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-3.1, 3.1),
                                                 rng.uniform(0, 0.8), 0.0, rng.uniform(-0.6, 0.6)))
     ga = (float(rng.uniform(0.1, 2.0)), 0.0, float(rng.uniform(0.2, 2.0)), float(rng.uniform(-3, 3)),
