@@ -121,6 +121,7 @@ class GridJob:
         self.params_kw = dict(sim_time=w.sim_time, sim_granularity=w.sim_granularity)
         prec = SFW_PRECISION_F32 if precision == "f32" else SFW_PRECISION_F64
         self.scorer = HipScorer(default_params(precision=prec, **self.params_kw), device=device)
+        self.scorer.set_timing(True)  # per-kernel HIP events for the roofline object
         self.scorer.load_scene(self.scene)
         from social_force_window_planner_amd import multi_gpu
 

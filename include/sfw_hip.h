@@ -211,8 +211,13 @@ int sfw_grid_sync(sfw_handle h);
 /* D2H of the cost vector (nullable) and the local selection (nullable). */
 int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out,
                    sfw_best_key *key_out);
-/* HIP-event time (ms) of the most recent sfw_grid_launch:
- * which = 0 whole launch, 1 rollout kernel, 2 social-force kernel, 3 argmin. */
+/* Per-kernel HIP events around the kernels of sfw_grid_launch, off by default
+ * (a control cycle is latency-bound; four event records cost as much as a
+ * kernel).  Measurement tooling (bench.py) switches them on. */
+int sfw_set_timing(sfw_handle h, int32_t enabled);
+/* HIP-event time (ms) of the most recent sfw_grid_launch (SFW_ERR_STATE unless
+ * timing was on): which = 0 whole launch, 1 rollout kernels, 2 social-force
+ * kernel, 3 argmin. */
 int sfw_last_launch_ms(sfw_handle h, int32_t which, float *ms_out);
 /* Optional dump of the per-step robot poses of sample `index` of the last
  * launch (Trajectory points for RViz markers, :366-374). */

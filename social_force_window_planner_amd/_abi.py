@@ -147,6 +147,7 @@ EXPORTED_SYMBOLS = (
     "sfw_grid_launch",
     "sfw_grid_sync",
     "sfw_grid_fetch",
+    "sfw_set_timing",
     "sfw_last_launch_ms",
     "sfw_grid_points",
     "sfw_grid_points_batch",

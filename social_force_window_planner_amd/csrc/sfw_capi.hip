@@ -89,22 +89,29 @@ struct sfw_planner_s {
   int n_chunks = 1;
   std::string err;
 
-  // world state
+  // world state.  The costmap has its own snapshot buffer (uploaded by sfw_set_costmap).  Footprint,
+  // agents, laser points, groups and the sample vectors are small: sfw_set_* keep them on the host
+  // and every stage packs them into ONE pinned arena and issues ONE H2D copy into `world`
+  // (device pointers below are offsets into it) — a control cycle is latency-bound and each
+  // separate copy costs as much as a kernel launch.
   dev_buf<uint8_t> cells;
   uint32_t size_x = 0, size_y = 0;
   double origin_x = 0, origin_y = 0, resolution = 0;
   bool have_costmap = false;
-  dev_buf<double> footprint;
+  std::vector<double> h_footprint;  // 2K
   int K = 0;
-  dev_buf<double> agent_pos, agent_vel, obstacles;
-  dev_buf<sfw_agent_const> agent_c;
-  dev_buf<int32_t> agent_grp, grp_off, grp_mem;
+  std::vector<char> h_agents;       // pos | vel | const | obstacles | grp | off | mem, 16-byte aligned parts
+  size_t ao_vel = 0, ao_cst = 0, ao_obs = 0, ao_grp = 0, ao_off = 0, ao_mem = 0;
+  int A = 0, O = 0, NG = 0, n_grp_mem = 0;
+  dev_buf<char> world;
+  const double *d_footprint = nullptr, *d_agent_pos = nullptr, *d_agent_vel = nullptr, *d_obstacles = nullptr;
+  const sfw_agent_const *d_agent_c = nullptr;
+  const int32_t *d_agent_grp = nullptr, *d_grp_off = nullptr, *d_grp_mem = nullptr;
+  const double *d_linvels = nullptr, *d_angvels = nullptr;
   dev_buf<uint32_t> pair_tab;  // rebuilt when the agent count changes
   int pair_tab_A = -1;
-  int A = 0, O = 0, NG = 0, n_grp_mem = 0;
 
   // staged grid
-  dev_buf<double> linvels, angvels;
   std::vector<double> h_lin, h_ang;
   int nv = 0, nw = 0;
   sfw_robot_state rs{};
@@ -112,19 +119,21 @@ struct sfw_planner_s {
   double vy_samp = 0.0;
   int skip_zero = 1;
   int64_t index_base = 0;
-  bool staged = false, launched = false;
+  bool staged = false, launched = false, launched_timed = false;
+  bool timing = false;  // sfw_set_timing: record the per-kernel events sfw_last_launch_ms reads
 
   // per-sample outputs + per-chunk table
   dev_buf<int32_t> status, coll_step;
-  dev_buf<double> base_cost, costs;
+  dev_buf<double> base_cost, costs;  // costs: T doubles followed by the sfw_sel record (one D2H fetches both)
   dev_buf<sfw_robot_step> rstep;
   dev_buf<sfw_pose_frame> frame;
   dev_buf<int16_t> fcode;
-  dev_buf<sfw_sel> partials, sel;
+  dev_buf<sfw_sel> partials;
+  sfw_sel *d_sel = nullptr;
   dev_buf<double> points;
   dev_buf<int32_t> n_points;
   size_t table_budget_bytes = size_t(2) << 30;  // K1->K2 robot-step table per chunk
-  pinned_buf pin_map, pin_fp, pin_agents, pin_grid, pin_out;
+  pinned_buf pin_map, pin_world, pin_out;
 };
 
 namespace {
@@ -168,8 +177,8 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.ga = h->ga;
   L.vy_samp = h->vy_samp;
   L.skip_zero_sample = h->skip_zero;
-  L.linvels = h->linvels.p;
-  L.angvels = h->angvels.p;
+  L.linvels = h->d_linvels;
+  L.angvels = h->d_angvels;
   L.nv = h->nv;
   L.nw = h->nw;
   L.chunk_begin = begin;
@@ -180,17 +189,17 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.origin_x = h->origin_x;
   L.origin_y = h->origin_y;
   L.resolution = h->resolution;
-  L.footprint = h->footprint.p;
+  L.footprint = h->d_footprint;
   L.K = h->K;
-  L.agent_pos = h->agent_pos.p;
-  L.agent_vel = h->agent_vel.p;
-  L.agent_c = h->agent_c.p;
+  L.agent_pos = h->d_agent_pos;
+  L.agent_vel = h->d_agent_vel;
+  L.agent_c = h->d_agent_c;
   L.A = h->A;
-  L.obstacles = h->obstacles.p;
+  L.obstacles = h->d_obstacles;
   L.O = h->O;
-  L.agent_grp = h->agent_grp.p;
-  L.grp_off = h->grp_off.p;
-  L.grp_mem = h->grp_mem.p;
+  L.agent_grp = h->d_agent_grp;
+  L.grp_off = h->d_grp_off;
+  L.grp_mem = h->d_grp_mem;
   L.NG = h->NG;
   L.n_grp_mem = h->n_grp_mem;
   sfw_derive(L);
@@ -214,17 +223,39 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     return fail(h, SFW_ERR_INVALID_ARG, "grid_stage: null pointer or non-positive sample count");
   if (!h->have_costmap) return fail(h, SFW_ERR_STATE, "grid_stage: no costmap set (sfw_set_costmap)");
   SFW_HIP(h, hipSetDevice(h->device));
-  SFW_HIP(h, h->linvels.reserve(nv));
-  SFW_HIP(h, h->angvels.reserve(nw));
   h->h_lin.assign(lin, lin + nv);
   h->h_ang.assign(ang, ang + nw);
-  SFW_HIP(h, h->pin_grid.reserve(sizeof(double) * (static_cast<size_t>(nv) + nw)));
-  std::memcpy(h->pin_grid.p, lin, sizeof(double) * nv);
-  std::memcpy(h->pin_grid.p + sizeof(double) * nv, ang, sizeof(double) * nw);
-  SFW_HIP(h, hipMemcpyAsync(h->linvels.p, h->pin_grid.p, sizeof(double) * nv, hipMemcpyHostToDevice, h->stream));
-  SFW_HIP(h, hipMemcpyAsync(h->angvels.p, h->pin_grid.p + sizeof(double) * nv, sizeof(double) * nw,
-                            hipMemcpyHostToDevice, h->stream));
-  SFW_HIP(h, h->pin_grid.mark(h->stream));
+  {  // one arena, one copy: footprint | agents blob | linvels | angvels
+    auto up16 = [](size_t b) { return (b + 15) & ~size_t(15); };
+    const size_t o_fp = 0, o_ag = o_fp + up16(sizeof(double) * (h->h_footprint.empty() ? 2 : h->h_footprint.size())),
+                 o_lin = o_ag + up16(h->h_agents.size()), o_ang = o_lin + up16(sizeof(double) * nv),
+                 total = o_ang + up16(sizeof(double) * nw);
+    SFW_HIP(h, h->pin_world.reserve(total));
+    SFW_HIP(h, h->world.reserve(total));
+    char *pb = h->pin_world.p;
+    if (!h->h_footprint.empty()) std::memcpy(pb + o_fp, h->h_footprint.data(), sizeof(double) * h->h_footprint.size());
+    if (!h->h_agents.empty()) std::memcpy(pb + o_ag, h->h_agents.data(), h->h_agents.size());
+    std::memcpy(pb + o_lin, lin, sizeof(double) * nv);
+    std::memcpy(pb + o_ang, ang, sizeof(double) * nw);
+    SFW_HIP(h, hipMemcpyAsync(h->world.p, pb, total, hipMemcpyHostToDevice, h->stream));
+    SFW_HIP(h, h->pin_world.mark(h->stream));
+    const char *db = h->world.p;
+    h->d_footprint = reinterpret_cast<const double *>(db + o_fp);
+    h->d_agent_pos = reinterpret_cast<const double *>(db + o_ag);
+    h->d_agent_vel = reinterpret_cast<const double *>(db + o_ag + h->ao_vel);
+    h->d_agent_c = reinterpret_cast<const sfw_agent_const *>(db + o_ag + h->ao_cst);
+    h->d_obstacles = reinterpret_cast<const double *>(db + o_ag + h->ao_obs);
+    h->d_agent_grp = reinterpret_cast<const int32_t *>(db + o_ag + h->ao_grp);
+    h->d_grp_off = reinterpret_cast<const int32_t *>(db + o_ag + h->ao_off);
+    h->d_grp_mem = reinterpret_cast<const int32_t *>(db + o_ag + h->ao_mem);
+    h->d_linvels = reinterpret_cast<const double *>(db + o_lin);
+    h->d_angvels = reinterpret_cast<const double *>(db + o_ang);
+  }
+  if (h->pair_tab_A != h->A) {
+    SFW_HIP(h, h->pair_tab.reserve(static_cast<size_t>(sfw_pair_table_entries(h->A))));
+    SFW_HIP(h, sfw_launch_pair_table(h->pair_tab.p, h->A, h->stream));
+    h->pair_tab_A = h->A;
+  }
   h->nv = nv;
   h->nw = nw;
   h->rs = *rs;
@@ -236,9 +267,9 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   SFW_HIP(h, h->status.reserve(T));
   SFW_HIP(h, h->coll_step.reserve(T));
   SFW_HIP(h, h->base_cost.reserve(T));
-  SFW_HIP(h, h->costs.reserve(T));
+  SFW_HIP(h, h->costs.reserve(T + (sizeof(sfw_sel) + sizeof(double) - 1) / sizeof(double)));
+  h->d_sel = reinterpret_cast<sfw_sel *>(h->costs.p + T);
   SFW_HIP(h, h->partials.reserve(sfw_argmin_partials(T)));
-  SFW_HIP(h, h->sel.reserve(1));
   // robot-step table: [S][chunk] records, chunk bounded by the table budget
   const int S = num_steps_of(h->params);
   int64_t chunk = static_cast<int64_t>(
@@ -266,10 +297,11 @@ int launch_common(sfw_handle h) {
   const size_t lds = sfw_social_lds_bytes(h->A, h->O, h->NG, h->n_grp_mem, chunk);
   if (h->A > 0 && lds > 160 * 1024)
     return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
-  SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  const bool timing = h->timing;
+  if (timing) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
   const bool single = chunk >= T;
   h->n_chunks = static_cast<int>((T + chunk - 1) / chunk);
-  if (!single) {
+  if (!single && timing) {
     while (h->chunk_ev.size() < static_cast<size_t>(3 * h->n_chunks)) {
       hipEvent_t e = nullptr;
       SFW_HIP(h, hipEventCreate(&e));
@@ -281,17 +313,18 @@ int launch_common(sfw_handle h) {
     const int64_t n = (T - b < chunk) ? (T - b) : chunk;
     sfw_launch L;
     fill_launch(h, L, b, n, chunk);
-    if (!single) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c], h->stream));
+    if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c], h->stream));
     SFW_HIP(h, sfw_launch_rollout(L, h->stream));
-    SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
+    if (timing) SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
     SFW_HIP(h, sfw_launch_social(L, h->stream));
-    if (!single) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c + 2], h->stream));
+    if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c + 2], h->stream));
   }
-  SFW_HIP(h, hipEventRecord(h->ev[2], h->stream));
-  SFW_HIP(h, sfw_launch_argmin(h->costs.p, h->linvels.p, h->angvels.p, h->nw, T, h->index_base,
-                               h->partials.p, h->sel.p, h->stream));
-  SFW_HIP(h, hipEventRecord(h->ev[3], h->stream));
+  if (timing) SFW_HIP(h, hipEventRecord(h->ev[2], h->stream));
+  SFW_HIP(h, sfw_launch_argmin(h->costs.p, h->d_linvels, h->d_angvels, h->nw, T, h->index_base,
+                               h->partials.p, h->d_sel, h->stream));
+  if (timing) SFW_HIP(h, hipEventRecord(h->ev[3], h->stream));
   h->launched = true;
+  h->launched_timed = timing;
   return SFW_OK;
 }
 
@@ -387,17 +420,8 @@ int sfw_destroy(sfw_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->cells.release();
-  h->footprint.release();
-  h->agent_pos.release();
-  h->agent_vel.release();
-  h->obstacles.release();
-  h->agent_c.release();
-  h->agent_grp.release();
-  h->grp_off.release();
-  h->grp_mem.release();
+  h->world.release();
   h->pair_tab.release();
-  h->linvels.release();
-  h->angvels.release();
   h->status.release();
   h->coll_step.release();
   h->base_cost.release();
@@ -406,13 +430,10 @@ int sfw_destroy(sfw_handle h) {
   h->frame.release();
   h->fcode.release();
   h->partials.release();
-  h->sel.release();
   h->points.release();
   h->n_points.release();
   h->pin_map.release();
-  h->pin_fp.release();
-  h->pin_agents.release();
-  h->pin_grid.release();
+  h->pin_world.release();
   h->pin_out.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
@@ -457,15 +478,7 @@ int sfw_set_costmap(sfw_handle h, const uint8_t *cells, uint32_t size_x, uint32_
 int sfw_set_footprint(sfw_handle h, const double *xy, int32_t K) {
   if (!h) return SFW_ERR_INVALID_ARG;
   if (K < 0 || (K > 0 && !xy)) return fail(h, SFW_ERR_INVALID_ARG, "set_footprint: bad arguments");
-  SFW_HIP(h, hipSetDevice(h->device));
-  SFW_HIP(h, h->footprint.reserve(static_cast<size_t>(2) * (K > 0 ? K : 1)));
-  if (K > 0) {
-    const size_t bytes = sizeof(double) * 2 * K;
-    SFW_HIP(h, h->pin_fp.reserve(bytes));
-    std::memcpy(h->pin_fp.p, xy, bytes);
-    SFW_HIP(h, hipMemcpyAsync(h->footprint.p, h->pin_fp.p, bytes, hipMemcpyHostToDevice, h->stream));
-    SFW_HIP(h, h->pin_fp.mark(h->stream));
-  }
+  h->h_footprint.assign(xy, xy + 2 * static_cast<size_t>(K));  // uploaded with the next stage
   h->K = K;
   return SFW_OK;
 }
@@ -474,7 +487,6 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   if (!h) return SFW_ERR_INVALID_ARG;
   if (A < 0 || O < 0 || (A > 0 && !agents) || (O > 0 && !obstacles_xy))
     return fail(h, SFW_ERR_INVALID_ARG, "set_agents: bad arguments");
-  SFW_HIP(h, hipSetDevice(h->device));
   const size_t An = static_cast<size_t>(A > 0 ? A : 1), On = static_cast<size_t>(O > 0 ? O : 1);
   // groups: dense index in order of first appearance, CSR member lists in agent order
   std::vector<int32_t> grp(An, -1), ids, off(1, 0), mem;
@@ -492,14 +504,14 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   }
   const int n_mem = off.back();
   if (mem.empty()) mem.push_back(0);
-  // one pinned arena: pos | vel | const | obstacles | grp | off | mem  (16-byte aligned parts)
+  // host blob (uploaded with the next stage): pos | vel | const | obstacles | grp | off | mem
   auto up16 = [](size_t b) { return (b + 15) & ~size_t(15); };
   const size_t o_pos = 0, o_vel = o_pos + up16(16 * An), o_cst = o_vel + up16(16 * An),
                o_obs = o_cst + up16(sizeof(sfw_agent_const) * An), o_grp = o_obs + up16(16 * On),
                o_off = o_grp + up16(4 * An), o_mem = o_off + up16(4 * off.size()),
                total = o_mem + up16(4 * mem.size());
-  SFW_HIP(h, h->pin_agents.reserve(total));
-  char *base = h->pin_agents.p;
+  h->h_agents.assign(total, 0);
+  char *base = h->h_agents.data();
   double *pos = reinterpret_cast<double *>(base + o_pos), *vel = reinterpret_cast<double *>(base + o_vel);
   sfw_agent_const *cst = reinterpret_cast<sfw_agent_const *>(base + o_cst);
   for (int i = 0; i < A; ++i) {
@@ -520,29 +532,12 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   std::memcpy(base + o_grp, grp.data(), 4 * grp.size());
   std::memcpy(base + o_off, off.data(), 4 * off.size());
   std::memcpy(base + o_mem, mem.data(), 4 * mem.size());
-  SFW_HIP(h, h->agent_pos.reserve(2 * An));
-  SFW_HIP(h, h->agent_vel.reserve(2 * An));
-  SFW_HIP(h, h->agent_c.reserve(An));
-  SFW_HIP(h, h->obstacles.reserve(2 * On));
-  SFW_HIP(h, h->agent_grp.reserve(An));
-  SFW_HIP(h, h->grp_off.reserve(off.size()));
-  SFW_HIP(h, h->grp_mem.reserve(mem.size()));
-  auto h2d = [&](void *dst, size_t o, size_t bytes) {
-    return bytes ? hipMemcpyAsync(dst, base + o, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
-  };
-  SFW_HIP(h, h2d(h->agent_pos.p, o_pos, 16 * static_cast<size_t>(A)));
-  SFW_HIP(h, h2d(h->agent_vel.p, o_vel, 16 * static_cast<size_t>(A)));
-  SFW_HIP(h, h2d(h->agent_c.p, o_cst, sizeof(sfw_agent_const) * static_cast<size_t>(A)));
-  SFW_HIP(h, h2d(h->obstacles.p, o_obs, 16 * static_cast<size_t>(O)));
-  SFW_HIP(h, h2d(h->agent_grp.p, o_grp, 4 * static_cast<size_t>(A)));
-  SFW_HIP(h, h2d(h->grp_off.p, o_off, 4 * off.size()));
-  SFW_HIP(h, h2d(h->grp_mem.p, o_mem, 4 * mem.size()));
-  SFW_HIP(h, h->pin_agents.mark(h->stream));
-  if (h->pair_tab_A != A) {
-    SFW_HIP(h, h->pair_tab.reserve(static_cast<size_t>(sfw_pair_table_entries(A))));
-    SFW_HIP(h, sfw_launch_pair_table(h->pair_tab.p, A, h->stream));
-    h->pair_tab_A = A;
-  }
+  h->ao_vel = o_vel;
+  h->ao_cst = o_cst;
+  h->ao_obs = o_obs;
+  h->ao_grp = o_grp;
+  h->ao_off = o_off;
+  h->ao_mem = o_mem;
   h->NG = static_cast<int>(ids.size());
   h->n_grp_mem = n_mem;
   h->A = A;
@@ -569,13 +564,15 @@ int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out, sfw_best
   if (!h->launched) return fail(h, SFW_ERR_STATE, "grid_fetch before grid_launch");
   SFW_HIP(h, hipSetDevice(h->device));
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
-  SFW_HIP(h, h->pin_out.reserve(sizeof(sfw_sel)));
-  if (costs_out)
-    SFW_HIP(h, hipMemcpyAsync(costs_out, h->costs.p, sizeof(double) * T, hipMemcpyDeviceToHost, h->stream));
-  SFW_HIP(h, hipMemcpyAsync(h->pin_out.p, h->sel.p, sizeof(sfw_sel), hipMemcpyDeviceToHost, h->stream));
+  // costs and the selection record are contiguous on the device: one copy fetches both
+  const size_t cost_bytes = costs_out ? sizeof(double) * static_cast<size_t>(T) : 0;
+  SFW_HIP(h, h->pin_out.reserve(cost_bytes + sizeof(sfw_sel)));
+  const char *src = reinterpret_cast<const char *>(h->d_sel) - cost_bytes;
+  SFW_HIP(h, hipMemcpyAsync(h->pin_out.p, src, cost_bytes + sizeof(sfw_sel), hipMemcpyDeviceToHost, h->stream));
   SFW_HIP(h, hipStreamSynchronize(h->stream));
+  if (costs_out) std::memcpy(costs_out, h->pin_out.p, cost_bytes);
   sfw_sel s;
-  std::memcpy(&s, h->pin_out.p, sizeof(s));
+  std::memcpy(&s, h->pin_out.p + cost_bytes, sizeof(s));
   sel_to_best(h, s, best_out, key_out);
   return SFW_OK;
 }
@@ -620,9 +617,16 @@ int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp, doubl
   return SFW_OK;
 }
 
+int sfw_set_timing(sfw_handle h, int32_t enabled) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  h->timing = enabled != 0;
+  return SFW_OK;
+}
+
 int sfw_last_launch_ms(sfw_handle h, int32_t which, float *ms_out) {
   if (!h || !ms_out) return SFW_ERR_INVALID_ARG;
   if (!h->launched) return fail(h, SFW_ERR_STATE, "last_launch_ms before grid_launch");
+  if (!h->launched_timed) return fail(h, SFW_ERR_STATE, "last_launch_ms: timing was off for the last launch (sfw_set_timing)");
   SFW_HIP(h, hipSetDevice(h->device));
   SFW_HIP(h, hipEventSynchronize(h->ev[3]));
   if (h->n_chunks > 1 && (which == 1 || which == 2)) {  // sum over the chunks of a multi-chunk launch

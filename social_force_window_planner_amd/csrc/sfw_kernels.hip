@@ -135,21 +135,21 @@ __device__ __forceinline__ float normalize_angle_f(float val, float mn, float mx
   return mx - fmodf(mn - val, mx - mn);
 }
 
-// K1a: sequential pose integration, one thread per sample.  Writes the
-// pre-step footprint frame (x_i, y_i, cos th_i, sin th_i) and the post-step robot
-// agent state for every step, plus the pedestrian-independent cost terms.
-__global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
-  const int64_t local = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (local >= L.chunk_count) return;
+// Sequential pose integration of one sample (reference :527-:611 without the costmap and the
+// pedestrians): hands the pre-step footprint frame (x_i, y_i, cos th_i, sin th_i) of every step to
+// `put_frame`, writes the post-step robot agent state per step and the pedestrian-independent cost
+// terms.  Returns false for the never-scored (0,0) sample.
+template <typename FrameSink>
+__device__ __forceinline__ bool rollout_sample(const sfw_launch &L, int64_t local, FrameSink &&put_frame) {
   const int64_t t = L.chunk_begin + local;
   const int iv = static_cast<int>(t / L.nw), iw = static_cast<int>(t % L.nw);
   const double vx_samp = L.linvels[iv], vth_samp = L.angvels[iw], vy_samp = L.vy_samp;
   if (L.skip_zero_sample && vx_samp == 0.0 && vth_samp == 0.0) {  // ref :349-352
     L.status[t] = SFW_ST_SKIPPED;
     L.costs[t] = SFW_COST_SKIPPED;
-    return;
+    return false;
   }
-  L.status[t] = SFW_ST_VALID;  // K1c downgrades it if a step is illegal
+  L.status[t] = SFW_ST_VALID;  // the costmap scan downgrades it if a step is illegal
   if (L.coll_step) L.coll_step[t] = -1;
   double x_i = L.rs.x, y_i = L.rs.y, th_i = L.rs.theta;
   double vx_i = L.rs.vx, vy_i = L.rs.vy, vth_i = L.rs.vtheta;
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
     sincos(th_i, &s, &c);
     sfw_pose_frame f;
     f.x = x_i; f.y = y_i; f.c = c; f.s = s;
-    L.frame[static_cast<int64_t>(i) * L.rstep_stride + local] = f;
+    put_frame(i, f);
     if (L.points) {                                       // ref :578
       double *pt = L.points + (local * S + i) * 3;
       pt[0] = x_i;
@@ -189,6 +189,40 @@ __global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
   ang = fabs(ang) / M_PI;
   const double vel = fabs(L.p.max_vel_x - vx_i) / L.p.max_vel_x;
   L.base_cost[t] = L.p.vel_weight * vel + L.p.distance_weight * d + L.p.angle_weight * ang;
+  return true;
+}
+
+// In-order consumption of a sample's per-step footprint costs (n_ok legal steps so far, running
+// sum cm): first illegal step rejects the trajectory (ref :555-573), otherwise costmap_cost
+// accumulates in step order (ref :575, :656).
+__device__ __forceinline__ bool scan_code(double fc, double &cm, int &n_ok) {
+  if (fc >= 254.0 || fc < 0) return false;
+  cm += fc / 255.0;
+  ++n_ok;
+  return true;
+}
+__device__ __forceinline__ void scan_finish(const sfw_launch &L, int64_t t, int64_t local, double cm, int n_ok) {
+  const int S = L.S;
+  if (L.n_points) L.n_points[local] = n_ok;
+  if (n_ok < S) {
+    L.status[t] = SFW_ST_INVALID;
+    L.costs[t] = SFW_COST_INVALID;
+    return;
+  }
+  cm = cm / S;
+  const double base = L.base_cost[t] + L.p.costmap_weight * cm;
+  L.base_cost[t] = base;
+  // No agent vector at all: social work is identically 0 and K2 is not launched.
+  if (L.A == 0) L.costs[t] = base + L.p.social_weight * 0.0;
+}
+
+// K1a: one thread per sample.
+__global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
+  const int64_t local = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (local >= L.chunk_count) return;
+  rollout_sample(L, local, [&](int i, const sfw_pose_frame &f) {
+    L.frame[static_cast<int64_t>(i) * L.rstep_stride + local] = f;
+  });
 }
 
 // K1b: footprint legality/cost of one pose, one thread per (step, sample).
@@ -205,9 +239,7 @@ __global__ void __launch_bounds__(256) sfw_footprint_kernel(const sfw_launch L) 
   L.fcode[step * L.rstep_stride + local] = static_cast<int16_t>(fc);
 }
 
-// K1c: in-order scan of the per-step footprint costs, one thread per sample:
-// first illegal step rejects the trajectory (ref :555-573), otherwise
-// costmap_cost accumulates in step order (ref :575, :656).
+// K1c: in-order scan of the per-step footprint costs, one thread per sample.
 __global__ void __launch_bounds__(256) sfw_costmap_scan_kernel(const sfw_launch L) {
   const int64_t local = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (local >= L.chunk_count) return;
@@ -227,25 +259,42 @@ __global__ void __launch_bounds__(256) sfw_costmap_scan_kernel(const sfw_launch 
     for (int j = 0; j < 8; ++j)
       v[j] = (base + j < S) ? L.fcode[static_cast<int64_t>(base + j) * L.rstep_stride + local] : int16_t(-1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const double fc = static_cast<double>(v[j]);
-      if (!stopped && base + j < S) {
-        if (fc >= 254.0 || fc < 0) stopped = true;
-        else { cm += fc / 255.0; ++n_ok; }
-      }
-    }
+    for (int j = 0; j < 8; ++j)
+      if (!stopped && base + j < S) stopped = !scan_code(static_cast<double>(v[j]), cm, n_ok);
   }
-  if (L.n_points) L.n_points[local] = n_ok;
-  if (n_ok < S) {
-    L.status[t] = SFW_ST_INVALID;
-    L.costs[t] = SFW_COST_INVALID;
+  scan_finish(L, t, local, cm, n_ok);
+}
+
+// K1 for small grids (a control cycle of the reference's own 5 x 9 samples): the three stages in
+// one launch, one 64-thread block per sample.  Lane 0 integrates the poses into LDS, the block's
+// lanes check one step's footprint each, lane 0 scans the codes in step order.  Same device
+// functions, same arithmetic, two kernel boundaries fewer on the latency path.
+constexpr int K1_SMALL_MAX_STEPS = 512;
+__global__ void __launch_bounds__(64) sfw_rollout_small_kernel(const sfw_launch L) {
+  __shared__ sfw_pose_frame fr[K1_SMALL_MAX_STEPS];
+  __shared__ int16_t code[K1_SMALL_MAX_STEPS];
+  __shared__ int scored;
+  const int64_t local = blockIdx.x;
+  const int64_t t = L.chunk_begin + local;
+  const int S = L.S;
+  if (threadIdx.x == 0) scored = rollout_sample(L, local, [&](int i, const sfw_pose_frame &f) { fr[i] = f; }) ? 1 : 0;
+  __syncthreads();
+  if (!scored) {
+    if (threadIdx.x == 0 && L.n_points) L.n_points[local] = 0;
     return;
   }
-  cm = cm / S;
-  const double base = L.base_cost[t] + L.p.costmap_weight * cm;
-  L.base_cost[t] = base;
-  // No agent vector at all: social work is identically 0 and K2 is not launched.
-  if (L.A == 0) L.costs[t] = base + L.p.social_weight * 0.0;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    const sfw_pose_frame f = fr[i];
+    code[i] = static_cast<int16_t>(footprint_cost(L, f.x, f.y, f.c, f.s));  // includes the ref :545 map check
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double cm = 0.0;
+    int n_ok = 0;
+    for (int i = 0; i < S; ++i)
+      if (!scan_code(static_cast<double>(code[i]), cm, n_ok)) break;
+    scan_finish(L, t, local, cm, n_ok);
+  }
 }
 
 #pragma clang fp contract(fast)
@@ -874,8 +923,11 @@ __global__ void __launch_bounds__(256) sfw_pair_table_kernel(uint32_t *tab, int 
   tab[u] = e;
 }
 
+#ifndef SFW_FLAT_WAVES
+#define SFW_FLAT_WAVES 1  // tuning knob (csrc/Makefile EXTRA): minimum waves per SIMD the flat kernel is compiled for
+#endif
 template <typename R, bool GROUPS, int CAP>
-__global__ void __launch_bounds__(WAVE) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
+__global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   (void)G_unused;
   const int lane = threadIdx.x;
@@ -1158,6 +1210,10 @@ hipError_t sfw_launch_pair_table(uint32_t *tab, int A, hipStream_t stream) {
 
 hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream) {
   if (L.chunk_count <= 0) return hipSuccess;
+  if (L.chunk_count <= 2048 && L.S <= K1_SMALL_MAX_STEPS) {  // latency path: one launch
+    hipLaunchKernelGGL(sfw_rollout_small_kernel, dim3(static_cast<unsigned>(L.chunk_count)), dim3(64), 0, stream, L);
+    return hipGetLastError();
+  }
   {
     const int block = 64;  // latency-bound serial rollout: spread the waves over all CUs
     const unsigned grid = static_cast<unsigned>((L.chunk_count + block - 1) / block);
@@ -1226,6 +1282,7 @@ hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream) {
 }
 
 int64_t sfw_argmin_partials(int64_t T) {
+  if (T <= 16 * ARGMIN_BLOCK) return 1;  // one block, one launch (latency path)
   int64_t blocks = (T + ARGMIN_BLOCK - 1) / ARGMIN_BLOCK;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
@@ -1236,6 +1293,11 @@ hipError_t sfw_launch_argmin(const double *costs, const double *linvels, const d
                              int64_t T, int64_t index_base, sfw_sel *partials, sfw_sel *out,
                              hipStream_t stream) {
   const int blocks = static_cast<int>(sfw_argmin_partials(T));
+  if (blocks == 1) {  // the single block's partial is the result
+    hipLaunchKernelGGL(sfw_argmin_stage1, dim3(1), dim3(ARGMIN_BLOCK), 0, stream, costs, linvels, angvels, nw, T,
+                       index_base, out);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(sfw_argmin_stage1, dim3(blocks), dim3(ARGMIN_BLOCK), 0, stream, costs, linvels,
                      angvels, nw, T, index_base, partials);
   hipLaunchKernelGGL(sfw_argmin_stage2, dim3(1), dim3(ARGMIN_BLOCK), 0, stream, partials, blocks, out);

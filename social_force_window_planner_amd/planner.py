@@ -26,7 +26,9 @@ from ._abi import (
 )
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfw_hip.so")
+# SFW_HIP_LIB: load another build of the same library (A/B kernel tuning in one GPU session;
+# boxes differ by ~10 % in sustained clocks, so variants are only comparable within one run)
+LIB_PATH = os.environ.get("SFW_HIP_LIB") or os.path.join(_HERE, "libsfw_hip.so")
 _lib = None
 
 
@@ -39,7 +41,7 @@ class SfwError(RuntimeError):
 def build(force=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles on CPU)."""
     csrc = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("sfw_capi.hip", "sfw_kernels.hip", "sfw_device.h")]
+    srcs = [os.path.join(csrc, f) for f in ("sfw_capi.hip", "sfw_kernels.hip", "sfw_device.h", "sfw_math.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "sfw_hip.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs)
@@ -80,6 +82,7 @@ def lib():
         L.sfw_grid_launch.argtypes = [vp]
         L.sfw_grid_sync.argtypes = [vp]
         L.sfw_grid_fetch.argtypes = [vp, vp, C.POINTER(SfwBest), C.POINTER(SfwBestKey)]
+        L.sfw_set_timing.argtypes = [vp, C.c_int32]
         L.sfw_last_launch_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
         L.sfw_grid_points.argtypes = [vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32)]
         L.sfw_grid_points_batch.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
@@ -198,6 +201,10 @@ class HipScorer:
         self._check(lib().sfw_grid_fetch(self._h, costs.ctypes.data if want_costs else None, C.byref(best),
                                          C.byref(key)), "sfw_grid_fetch")
         return costs, best.as_dict(), key.as_tuple()
+
+    def set_timing(self, enabled=True):
+        """Per-kernel HIP events for last_launch_ms (off by default: latency path)."""
+        self._check(lib().sfw_set_timing(self._h, 1 if enabled else 0), "sfw_set_timing")
 
     def last_launch_ms(self, which=0):
         ms = C.c_float()

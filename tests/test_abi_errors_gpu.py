@@ -91,3 +91,22 @@ def test_many_agents_use_the_flat_kernel(oracle_mod, hip_mod):
     if v.any():
         assert np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= 1e-9
     assert gb["index"] == ob["index"]
+
+
+def test_timing_is_opt_in(hip_mod):
+    """sfw_last_launch_ms needs sfw_set_timing(1) before the launch; timed and untimed launches
+    give the same costs."""
+    L = hip_mod.lib()
+    scene = syn.make_scene("ref5x9")
+    g = hip_mod.HipScorer(default_params())
+    g.load_scene(scene)
+    c0, b0 = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    ms = C.c_float(0)
+    assert L.sfw_last_launch_ms(g._h, 0, C.byref(ms)) == SFW_ERR_STATE and b"timing" in L.sfw_last_error(g._h)
+    g.set_timing(True)
+    c1, b1 = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert np.array_equal(c0, c1) and b0 == b1
+    total = g.last_launch_ms(0)
+    parts = [g.last_launch_ms(k) for k in (1, 2, 3)]
+    assert total > 0 and all(p >= 0 for p in parts) and sum(parts) <= total * 1.05
+    assert L.sfw_last_launch_ms(g._h, 7, C.byref(ms)) == SFW_ERR_INVALID_ARG

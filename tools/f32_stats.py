@@ -18,7 +18,7 @@ for name, kw in cases:
     o = OracleScorer(default_params(**pk)); o.load_scene(sc)
     oc, ob = o.score_grid(sc.robot_state, sc.linvels, sc.angvels, sc.goal_args, n_threads=os.cpu_count())
     for prec in (0, 1):
-        g = HipScorer(default_params(precision=prec, **pk)); g.load_scene(sc)
+        g = HipScorer(default_params(precision=prec, **pk)); g.set_timing(True); g.load_scene(sc)
         gc, gb = g.score_grid(sc.robot_state, sc.linvels, sc.angvels, sc.goal_args)
         t0 = time.perf_counter(); g.stage(sc.robot_state, sc.linvels, sc.angvels, sc.goal_args); g.launch(); g.sync(); 
         ms = g.last_launch_ms(2)
