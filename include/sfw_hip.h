@@ -165,6 +165,10 @@ const char *sfw_last_error(sfw_handle h);
 int sfw_set_costmap(sfw_handle h, const uint8_t *cells, uint32_t size_x,
                     uint32_t size_y, double origin_x, double origin_y,
                     double resolution);
+/* sfw_set_footprint / sfw_set_agents keep a host copy; the next stage
+ * (sfw_grid_stage, sfw_score_grid, sfw_score_one) uploads footprint, agents,
+ * laser points and the sample vectors in ONE copy.  A sfw_grid_launch without
+ * a new stage keeps using what the last stage uploaded. */
 /* xy: K points (x0,y0,x1,y1,...) in the robot frame = footprint_spec_
  * (src/sfw_planner.cpp:32).  K < 3 => centre-cell check only
  * (src/costmap_model.cpp:41-48). */
@@ -198,7 +202,8 @@ int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp,
                   int32_t *n_points);
 
 /* ---- device-resident pipeline (what sfw_score_grid is made of) --------- */
-/* Stage one grid call: H2D of the sample vectors + robot state.  index_base
+/* Stage one grid call: one H2D copy of footprint, agents, laser points and
+ * the sample vectors; robot state and goal arguments are recorded.  index_base
  * is the global iteration index of this rank's first sample (multi-GPU
  * sharding by linvel rows); 0 on a single GPU. */
 int sfw_grid_stage(sfw_handle h, const sfw_robot_state *rs,

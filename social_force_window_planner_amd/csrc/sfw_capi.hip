@@ -103,6 +103,9 @@ struct sfw_planner_s {
   std::vector<char> h_agents;       // pos | vel | const | obstacles | grp | off | mem, 16-byte aligned parts
   size_t ao_vel = 0, ao_cst = 0, ao_obs = 0, ao_grp = 0, ao_off = 0, ao_mem = 0;
   int A = 0, O = 0, NG = 0, n_grp_mem = 0;
+  // what the last stage uploaded (sfw_set_* after a stage take effect at the next stage; a launch
+  // in between must keep describing the device copy)
+  int st_K = 0, st_A = 0, st_O = 0, st_NG = 0, st_n_grp_mem = 0;
   dev_buf<char> world;
   const double *d_footprint = nullptr, *d_agent_pos = nullptr, *d_agent_vel = nullptr, *d_obstacles = nullptr;
   const sfw_agent_const *d_agent_c = nullptr;
@@ -190,18 +193,18 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.origin_y = h->origin_y;
   L.resolution = h->resolution;
   L.footprint = h->d_footprint;
-  L.K = h->K;
+  L.K = h->st_K;
   L.agent_pos = h->d_agent_pos;
   L.agent_vel = h->d_agent_vel;
   L.agent_c = h->d_agent_c;
-  L.A = h->A;
+  L.A = h->st_A;
   L.obstacles = h->d_obstacles;
-  L.O = h->O;
+  L.O = h->st_O;
   L.agent_grp = h->d_agent_grp;
   L.grp_off = h->d_grp_off;
   L.grp_mem = h->d_grp_mem;
-  L.NG = h->NG;
-  L.n_grp_mem = h->n_grp_mem;
+  L.NG = h->st_NG;
+  L.n_grp_mem = h->st_n_grp_mem;
   sfw_derive(L);
   L.pair_tab = h->pair_tab.p;
   L.status = h->status.p;
@@ -251,6 +254,11 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     h->d_linvels = reinterpret_cast<const double *>(db + o_lin);
     h->d_angvels = reinterpret_cast<const double *>(db + o_ang);
   }
+  h->st_K = h->K;
+  h->st_A = h->A;
+  h->st_O = h->O;
+  h->st_NG = h->NG;
+  h->st_n_grp_mem = h->n_grp_mem;
   if (h->pair_tab_A != h->A) {
     SFW_HIP(h, h->pair_tab.reserve(static_cast<size_t>(sfw_pair_table_entries(h->A))));
     SFW_HIP(h, sfw_launch_pair_table(h->pair_tab.p, h->A, h->stream));
@@ -294,8 +302,8 @@ int launch_common(sfw_handle h) {
   int64_t chunk = static_cast<int64_t>(std::min(h->rstep.cap, std::min(h->frame.cap, h->fcode.cap)) / S);
   if (chunk > T) chunk = T;
   if (chunk < 1) return fail(h, SFW_ERR_STATE, "robot-step table too small (params changed after stage?)");
-  const size_t lds = sfw_social_lds_bytes(h->A, h->O, h->NG, h->n_grp_mem, chunk);
-  if (h->A > 0 && lds > 160 * 1024)
+  const size_t lds = sfw_social_lds_bytes(h->st_A, h->st_O, h->st_NG, h->st_n_grp_mem, chunk);
+  if (h->st_A > 0 && lds > 160 * 1024)
     return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
   const bool timing = h->timing;
   if (timing) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));

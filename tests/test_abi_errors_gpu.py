@@ -110,3 +110,30 @@ def test_timing_is_opt_in(hip_mod):
     parts = [g.last_launch_ms(k) for k in (1, 2, 3)]
     assert total > 0 and all(p >= 0 for p in parts) and sum(parts) <= total * 1.05
     assert L.sfw_last_launch_ms(g._h, 7, C.byref(ms)) == SFW_ERR_INVALID_ARG
+
+
+def test_world_changes_between_stage_and_launch(oracle_mod, hip_mod):
+    """sfw_set_agents after a stage takes effect at the NEXT stage: a launch in between still
+    scores the staged world (and does not read past the uploaded agent arrays)."""
+    w5 = dataclasses.replace(syn.WORKLOADS["ref5x9"], n_people=5)
+    w40 = dataclasses.replace(syn.WORKLOADS["ref5x9"], n_people=40, seed=8)
+    s5, s40 = syn.make_scene(w5), syn.make_scene(w40)
+    g = hip_mod.HipScorer(default_params())
+    g.load_scene(s5)
+    g.stage(s5.robot_state, s5.linvels, s5.angvels, s5.goal_args)
+    g.set_agents(s40.agents, s40.obstacles)  # more agents than the device copy holds
+    g.launch()
+    c_staged, b_staged, _ = g.fetch(want_costs=True)
+    o = oracle_mod.OracleScorer(default_params())
+    o.load_scene(s5)
+    oc, ob = o.score_grid(s5.robot_state, s5.linvels, s5.angvels, s5.goal_args)
+    v = oc >= 0
+    assert np.array_equal(oc < 0, c_staged < 0) and np.max(np.abs(c_staged[v] - oc[v]) / np.abs(oc[v])) <= 1e-9
+    assert b_staged["index"] == ob["index"]
+    # the next stage picks the new agent set up
+    c2, b2 = g.score_grid(s5.robot_state, s5.linvels, s5.angvels, s5.goal_args)
+    o.set_agents(s40.agents, s40.obstacles)
+    oc2, ob2 = o.score_grid(s5.robot_state, s5.linvels, s5.angvels, s5.goal_args)
+    v = oc2 >= 0
+    assert np.array_equal(oc2 < 0, c2 < 0) and np.max(np.abs(c2[v] - oc2[v]) / np.abs(oc2[v])) <= 1e-9
+    assert b2["index"] == ob2["index"]
