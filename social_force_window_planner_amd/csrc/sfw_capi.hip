@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -125,6 +126,16 @@ struct sfw_planner_s {
   bool staged = false, launched = false, launched_timed = false;
   bool timing = false;  // sfw_set_timing: record the per-kernel events sfw_last_launch_ms reads
 
+  // shared-prefix plan of the staged grid (sfw_device.h: sfw_cls_agent); P == 0: not used
+  struct chunk_classes { int32_t n_row_cls; size_t o_row_cls, o_row_rep; };  // offsets (ints) into d_cls
+  int prefix_P = 0, prefix_S = 0, prefix_ncol = 0;
+  int64_t prefix_chunk = 0;
+  size_t prefix_o_col_cls = 0, prefix_o_col_rep = 0;
+  std::vector<chunk_classes> prefix_chunks;
+  dev_buf<int32_t> d_cls, cls_dead;
+  dev_buf<sfw_cls_agent> cls_state;
+  int prefix_env = -1;  // SFW_PREFIX: -1 automatic, 0 off, >0 forced split step
+
   // per-sample outputs + per-chunk table
   dev_buf<int32_t> status, coll_step;
   dev_buf<double> base_cost, costs;  // costs: T doubles followed by the sfw_sel record (one D2H fetches both)
@@ -136,7 +147,7 @@ struct sfw_planner_s {
   dev_buf<double> points;
   dev_buf<int32_t> n_points;
   size_t table_budget_bytes = size_t(2) << 30;  // K1->K2 robot-step table per chunk
-  pinned_buf pin_map, pin_world, pin_out;
+  pinned_buf pin_map, pin_world, pin_out, pin_cls;
 };
 
 namespace {
@@ -219,6 +230,112 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.n_points = nullptr;
 }
 
+// ---- shared-prefix plan ---------------------------------------------------
+// reference sfw_planner.hpp:457-463, the recurrence K1a runs on the device (same IEEE operations)
+double new_velocity_host(double vg, double vi, double a_max, double dt) {
+  if ((vg - vi) >= 0) return std::fmin(vg, vi + a_max * dt);
+  return std::fmax(vg, vi - a_max * dt);
+}
+
+// Classes of the samples' velocity sequences after 1..max_p steps: cls[p-1][i] is the class of
+// sample value i when the first p velocities are compared, counts[p-1] the number of classes.
+void velocity_classes(const std::vector<double> &targets, double v0, double a_max, double dt, int max_p,
+                      std::vector<std::vector<int32_t>> &cls, std::vector<int32_t> &counts) {
+  const size_t n = targets.size();
+  std::vector<double> v(n, v0);
+  std::vector<int32_t> cur(n, 0);
+  cls.clear();
+  counts.clear();
+  for (int p = 0; p < max_p; ++p) {
+    std::map<std::pair<int32_t, uint64_t>, int32_t> ids;
+    for (size_t i = 0; i < n; ++i) {
+      v[i] = new_velocity_host(targets[i], v[i], a_max, dt);
+      uint64_t bits;
+      std::memcpy(&bits, &v[i], sizeof(bits));
+      auto it = ids.emplace(std::make_pair(cur[i], bits), static_cast<int32_t>(ids.size())).first;
+      cur[i] = it->second;
+    }
+    cls.push_back(cur);
+    counts.push_back(static_cast<int32_t>(ids.size()));
+  }
+}
+
+// Decide the split step P of the staged grid and lay the class tables out per chunk of whole rows.
+int plan_prefix(sfw_handle h, int64_t chunk, int S) {
+  h->prefix_P = 0;
+  h->prefix_chunks.clear();
+  const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
+  if (h->prefix_env == 0 || h->st_A < 2 || S < 2 || h->vy_samp != 0.0) return SFW_OK;
+  if (h->prefix_env < 0 && T < 4096) return SFW_OK;  // the GPU is not full: an extra launch costs more than it saves
+  const double dt = h->params.sim_time / S;
+  const int max_p = std::min(S - 1, 48);
+  std::vector<std::vector<int32_t>> rc, cc;
+  std::vector<int32_t> nr, nc;
+  velocity_classes(h->h_lin, h->rs.vx, h->ga.acc_x, dt, max_p, rc, nr);
+  velocity_classes(h->h_ang, h->rs.vtheta, h->ga.acc_theta, dt, max_p, cc, nc);
+  int best_p = 0;
+  double best_saved = 0.0;
+  for (int p = 1; p <= max_p; ++p) {
+    const double saved = (static_cast<double>(T) - static_cast<double>(nr[p - 1]) * nc[p - 1]) * p;
+    if (saved > best_saved) { best_saved = saved; best_p = p; }
+  }
+  if (h->prefix_env > 0) best_p = std::min(h->prefix_env, max_p);
+  else if (best_saved < 0.05 * static_cast<double>(T) * S) return SFW_OK;
+  if (best_p < 1) return SFW_OK;
+  // chunks of whole rows
+  int64_t rows_per_chunk = chunk / h->nw;
+  if (rows_per_chunk < 1) return SFW_OK;  // a single row does not fit the table budget: no sharing
+  const std::vector<int32_t> &row_cls_g = rc[best_p - 1], &col_cls = cc[best_p - 1];
+  const int ncol = nc[best_p - 1];
+  std::vector<int32_t> ints;  // col_cls | col_rep | per chunk: row_cls (local) | row_rep (local rows)
+  h->prefix_o_col_cls = ints.size();
+  ints.insert(ints.end(), col_cls.begin(), col_cls.end());
+  h->prefix_o_col_rep = ints.size();
+  {
+    std::vector<int32_t> rep(ncol, -1);
+    for (int i = 0; i < h->nw; ++i)
+      if (rep[col_cls[i]] < 0) rep[col_cls[i]] = i;
+    ints.insert(ints.end(), rep.begin(), rep.end());
+  }
+  int64_t max_cls = 0;
+  for (int64_t r0 = 0; r0 < h->nv; r0 += rows_per_chunk) {
+    const int64_t r1 = std::min<int64_t>(h->nv, r0 + rows_per_chunk);
+    std::map<int32_t, int32_t> local;
+    std::vector<int32_t> lc, rep;
+    for (int64_t r = r0; r < r1; ++r) {
+      auto it = local.find(row_cls_g[r]);
+      if (it == local.end()) {
+        it = local.emplace(row_cls_g[r], static_cast<int32_t>(rep.size())).first;
+        rep.push_back(static_cast<int32_t>(r - r0));
+      }
+      lc.push_back(it->second);
+    }
+    sfw_planner_s::chunk_classes c;
+    c.n_row_cls = static_cast<int32_t>(rep.size());
+    c.o_row_cls = ints.size();
+    ints.insert(ints.end(), lc.begin(), lc.end());
+    c.o_row_rep = ints.size();
+    ints.insert(ints.end(), rep.begin(), rep.end());
+    h->prefix_chunks.push_back(c);
+    max_cls = std::max<int64_t>(max_cls, static_cast<int64_t>(c.n_row_cls) * ncol);
+  }
+  SFW_HIP(h, h->d_cls.reserve(ints.size()));
+  SFW_HIP(h, h->pin_cls.reserve(sizeof(int32_t) * ints.size()));
+  std::memcpy(h->pin_cls.p, ints.data(), sizeof(int32_t) * ints.size());
+  SFW_HIP(h, hipMemcpyAsync(h->d_cls.p, h->pin_cls.p, sizeof(int32_t) * ints.size(), hipMemcpyHostToDevice, h->stream));
+  SFW_HIP(h, h->pin_cls.mark(h->stream));
+  SFW_HIP(h, h->cls_dead.reserve(static_cast<size_t>(max_cls)));
+  SFW_HIP(h, h->cls_state.reserve(static_cast<size_t>(max_cls) * h->st_A));
+  if (std::getenv("SFW_DEBUG_PLAN"))
+    std::fprintf(stderr, "[sfw] shared prefix: P=%d of S=%d, %d x %d classes of %d x %d samples, %zu chunk(s)\n", best_p, S,
+                 nr[best_p - 1], ncol, h->nv, h->nw, h->prefix_chunks.size());
+  h->prefix_P = best_p;
+  h->prefix_S = S;
+  h->prefix_ncol = ncol;
+  h->prefix_chunk = rows_per_chunk * h->nw;
+  return SFW_OK;
+}
+
 int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int32_t nv, const double *ang,
                  int32_t nw, const sfw_goal_args *args, double vy_samp, int skip_zero, int64_t index_base) {
   if (!h) return SFW_ERR_INVALID_ARG;
@@ -287,6 +404,7 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   SFW_HIP(h, h->rstep.reserve(static_cast<size_t>(chunk) * S));
   SFW_HIP(h, h->frame.reserve(static_cast<size_t>(chunk) * S));
   SFW_HIP(h, h->fcode.reserve(static_cast<size_t>(chunk) * S));
+  if (int e = plan_prefix(h, chunk, S)) return e;
   h->staged = true;
   h->launched = false;
   return SFW_OK;
@@ -305,6 +423,9 @@ int launch_common(sfw_handle h) {
   const size_t lds = sfw_social_lds_bytes(h->st_A, h->st_O, h->st_NG, h->st_n_grp_mem, chunk);
   if (h->st_A > 0 && lds > 160 * 1024)
     return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
+  // the shared-prefix plan was laid out for the staged step count and for chunks of whole rows
+  const bool prefix = h->prefix_P > 0 && h->prefix_S == S && h->prefix_P < S && h->prefix_chunk <= chunk;
+  if (prefix) chunk = h->prefix_chunk;
   const bool timing = h->timing;
   if (timing) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
   const bool single = chunk >= T;
@@ -324,7 +445,24 @@ int launch_common(sfw_handle h) {
     if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c], h->stream));
     SFW_HIP(h, sfw_launch_rollout(L, h->stream));
     if (timing) SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
-    SFW_HIP(h, sfw_launch_social(L, h->stream));
+    if (prefix) {
+      const sfw_planner_s::chunk_classes &cc = h->prefix_chunks[static_cast<size_t>(c)];
+      L.step_split = h->prefix_P;
+      L.n_col_cls = h->prefix_ncol;
+      L.n_cls = cc.n_row_cls * h->prefix_ncol;
+      L.row_cls = h->d_cls.p + cc.o_row_cls;
+      L.row_rep = h->d_cls.p + cc.o_row_rep;
+      L.col_cls = h->d_cls.p + h->prefix_o_col_cls;
+      L.col_rep = h->d_cls.p + h->prefix_o_col_rep;
+      L.cls_state = h->cls_state.p;
+      L.cls_dead = h->cls_dead.p;
+      L.phase = SFW_PHASE_PREFIX;
+      SFW_HIP(h, sfw_launch_social(L, h->stream));
+      L.phase = SFW_PHASE_SUFFIX;
+      SFW_HIP(h, sfw_launch_social(L, h->stream));
+    } else {
+      SFW_HIP(h, sfw_launch_social(L, h->stream));
+    }
     if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c + 2], h->stream));
   }
   if (timing) SFW_HIP(h, hipEventRecord(h->ev[2], h->stream));
@@ -408,6 +546,7 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
   if (!h) return SFW_ERR_HIP;
   h->params = *params;
   h->device = device;
+  if (const char *b = std::getenv("SFW_PREFIX")) h->prefix_env = std::atoi(b);
   if (const char *b = std::getenv("SFW_TABLE_BUDGET_MB")) {
     long mb = std::atol(b);
     if (mb > 0) h->table_budget_bytes = static_cast<size_t>(mb) << 20;
@@ -443,6 +582,10 @@ int sfw_destroy(sfw_handle h) {
   h->pin_map.release();
   h->pin_world.release();
   h->pin_out.release();
+  h->pin_cls.release();
+  h->d_cls.release();
+  h->cls_dead.release();
+  h->cls_state.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto &e : h->chunk_ev)

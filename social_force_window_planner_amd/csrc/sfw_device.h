@@ -44,6 +44,20 @@ struct sfw_derived {
   double f_desired, inv_tau, rr, inv_O;
 };
 
+// Shared-prefix rollout (K2).  Under the acceleration limits the robot's first P steps are
+// bit-identical for every sample of a CLASS (same clipped linear-velocity sequence x same clipped
+// angular-velocity sequence), hence so is the whole pedestrian simulation of those steps.  Phase 1
+// runs steps [0,P) once per class and leaves this record per (class, agent); phase 2 resumes every
+// sample from its class's record for steps [P,S).  Same arithmetic on the same values in the same
+// order: costs are bit-identical to the unshared rollout.
+struct sfw_cls_agent {
+  double px, py, vx, vy;  // state after step P-1
+  double fx, fy;          // desired + obstacle (+ group) force at that state = step P's starting force
+  double sw;              // the agent slot's social-work sum over steps [0,P)
+  int32_t hasgoal, pad;
+};
+enum { SFW_PHASE_WHOLE = 0, SFW_PHASE_PREFIX = 1, SFW_PHASE_SUFFIX = 2 };
+
 // Everything the kernels need that is uniform over a launch.
 struct sfw_launch {
   // scoring parameters
@@ -81,6 +95,16 @@ struct sfw_launch {
   const int32_t *grp_mem;          // grp_off[NG] member agent indices, ascending per group
   int32_t NG;
   int32_t n_grp_mem;
+  // shared-prefix rollout (see sfw_cls_agent); chunks are whole grid rows when phase != WHOLE
+  int32_t phase;                 // SFW_PHASE_*
+  int32_t step_split;            // P
+  int32_t n_cls, n_col_cls;      // classes in this chunk = row classes x column classes
+  const int32_t *row_cls;        // [chunk rows]   row (linvel) class of a chunk-local row
+  const int32_t *row_rep;        // [row classes]  chunk-local row representing a row class
+  const int32_t *col_cls;        // [nw]           column (angvel) class
+  const int32_t *col_rep;        // [n_col_cls]    column representing a column class
+  sfw_cls_agent *cls_state;      // [n_cls][A]
+  int32_t *cls_dead;             // [n_cls] 0, or 2 + step of a pedestrian contact inside the prefix
   // flat social kernel: pair u -> packed LDS byte offsets (16*i | 16*j << 16), see sfw_launch_pair_table
   const uint32_t *pair_tab;
   // per-sample outputs, indexed by GLOBAL sample index

@@ -138,18 +138,21 @@ __device__ __forceinline__ float normalize_angle_f(float val, float mn, float mx
 // Sequential pose integration of one sample (reference :527-:611 without the costmap and the
 // pedestrians): hands the pre-step footprint frame (x_i, y_i, cos th_i, sin th_i) of every step to
 // `put_frame`, writes the post-step robot agent state per step and the pedestrian-independent cost
-// terms.  Returns false for the never-scored (0,0) sample.
+// terms.  Returns false for the never-scored (0,0) sample (whose records are written all the same).
 template <typename FrameSink>
 __device__ __forceinline__ bool rollout_sample(const sfw_launch &L, int64_t local, FrameSink &&put_frame) {
   const int64_t t = L.chunk_begin + local;
   const int iv = static_cast<int>(t / L.nw), iw = static_cast<int>(t % L.nw);
   const double vx_samp = L.linvels[iv], vth_samp = L.angvels[iw], vy_samp = L.vy_samp;
-  if (L.skip_zero_sample && vx_samp == 0.0 && vth_samp == 0.0) {  // ref :349-352
+  // The never-scored (0,0) sample (ref :349-352) still gets its robot-step records: it can be the
+  // representative of a shared-prefix class (sfw_cls_agent) whose other members are scored.
+  const bool scored = !(L.skip_zero_sample && vx_samp == 0.0 && vth_samp == 0.0);
+  if (!scored) {
     L.status[t] = SFW_ST_SKIPPED;
     L.costs[t] = SFW_COST_SKIPPED;
-    return false;
+  } else {
+    L.status[t] = SFW_ST_VALID;  // the costmap scan downgrades it if a step is illegal
   }
-  L.status[t] = SFW_ST_VALID;  // the costmap scan downgrades it if a step is illegal
   if (L.coll_step) L.coll_step[t] = -1;
   double x_i = L.rs.x, y_i = L.rs.y, th_i = L.rs.theta;
   double vx_i = L.rs.vx, vy_i = L.rs.vy, vth_i = L.rs.vtheta;
@@ -189,7 +192,7 @@ __device__ __forceinline__ bool rollout_sample(const sfw_launch &L, int64_t loca
   ang = fabs(ang) / M_PI;
   const double vel = fabs(L.p.max_vel_x - vx_i) / L.p.max_vel_x;
   L.base_cost[t] = L.p.vel_weight * vel + L.p.distance_weight * d + L.p.angle_weight * ang;
-  return true;
+  return scored;
 }
 
 // In-order consumption of a sample's per-step footprint costs (n_ok legal steps so far, running
@@ -639,6 +642,24 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_l
 
 // Stage the per-launch constants and the initial agent state into LDS; returns
 // false when every sample of this wave was already rejected by K1.
+// Work items of a K2 launch: samples of the chunk (whole rollout, suffix phase) or classes of the
+// chunk (prefix phase, see sfw_cls_agent).
+__device__ __forceinline__ int64_t item_count(const sfw_launch &L) {
+  return L.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L.n_cls) : L.chunk_count;
+}
+__device__ __forceinline__ int64_t class_of_sample(const sfw_launch &L, int64_t local) {
+  const int64_t row = local / L.nw, col = local - row * L.nw;  // chunks are whole rows when classes exist
+  return static_cast<int64_t>(L.row_cls[row]) * L.n_col_cls + L.col_cls[col];
+}
+// chunk-local sample whose K1 robot-step records an item reads
+__device__ __forceinline__ int64_t robot_sample_of_item(const sfw_launch &L, int64_t item) {
+  if (L.phase != SFW_PHASE_PREFIX) return item;
+  const int64_t rc = item / L.n_col_cls, cc = item - rc * L.n_col_cls;
+  return static_cast<int64_t>(L.row_rep[rc]) * L.nw + L.col_rep[cc];
+}
+
+// Stage the per-launch constants and the initial dead flags into LDS; returns false when no item of
+// this wave is live (rejected by K1, or by a pedestrian contact inside the shared prefix).
 template <bool GROUPS, bool CONSTS>
 __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout &s, int lane, int G, int Gn,
                                            int64_t first_local) {
@@ -661,7 +682,14 @@ __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout
   }
   if (lane < G) {
     int dead = 1;
-    if (lane < Gn) dead = (L.status[L.chunk_begin + first_local + lane] != SFW_ST_VALID);
+    if (lane < Gn) {
+      if (L.phase == SFW_PHASE_PREFIX) {
+        dead = 0;  // a class is simulated whatever K1 said about its members
+      } else {
+        dead = (L.status[L.chunk_begin + first_local + lane] != SFW_ST_VALID);
+        if (L.phase == SFW_PHASE_SUFFIX && dead == 0) dead = L.cls_dead[class_of_sample(L, first_local + lane)];
+      }
+    }
     s.dead[lane] = dead;
   }
   __syncthreads();
@@ -729,16 +757,22 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   constexpr int CAP = WAVE * NS;             // GA <= CAP: state arrays at compile-time distances
   constexpr int VEL = 16 * CAP, FRJ = 32 * CAP;  // byte offsets of vel[] / frj[] from pos[]
   const int lane = threadIdx.x;
-  const int A = L.A, O = L.O, S = L.S;
+  const int A = L.A, O = L.O;
   const int GA = G * A;
   const int NG = GROUPS ? L.NG : 0;  // GROUPS=false instantiation: no group code, lean register budget
   const lds_layout s(smem, A, CAP, GA, G, O, NG, GROUPS ? L.n_grp_mem : 0, true, false);
   const int64_t first_local = static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x)) * G;
-  const int64_t remain = L.chunk_count - first_local;
+  const int64_t remain = item_count(L) - first_local;
   const int Gn = remain < G ? static_cast<int>(remain) : G;
+  const int step_begin = L.phase == SFW_PHASE_SUFFIX ? L.step_split : 0;
+  const int step_end = L.phase == SFW_PHASE_PREFIX ? L.step_split : L.S;
   const sfm_consts<R> k = make_consts<R, false>(L);
   const double inv_O = L.k.inv_O;
-  if (!stage_wave<GROUPS, true>(L, s, lane, G, Gn, first_local)) return;
+  if (!stage_wave<GROUPS, true>(L, s, lane, G, Gn, first_local)) {
+    // nothing to integrate; samples that inherit a contact from their class still get their verdict
+    if (L.phase == SFW_PHASE_SUFFIX) finish_wave(L, s, lane, G, Gn, GA, first_local, 0.0);
+    return;
+  }
 
   // ---- this lane's slots --------------------------------------------------
   int sl_[NS], g_[NS], i_[NS];
@@ -758,11 +792,27 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     i_[r] = slc - g_[r] * A;
     sl_[r] = slc;
     const int i = i_[r];
+    fx[r] = fy[r] = sw[r] = 0.0;
+    if (L.phase == SFW_PHASE_SUFFIX) {  // resume from the class record
+      if (ok_[r] && g_[r] < Gn) {
+        const sfw_cls_agent c = L.cls_state[class_of_sample(L, first_local + g_[r]) * A + i];
+        s.pos[sl] = double2{c.px, c.py};
+        s.vel[sl] = double2{c.vx, c.vy};
+        s.frj[sl] = double2{0.0, 0.0};
+        s.hasgoal[sl] = c.hasgoal;
+        fx[r] = c.fx;
+        fy[r] = c.fy;
+        sw[r] = c.sw;
+      } else if (ok_[r]) {
+        s.pos[sl] = s.vel[sl] = s.frj[sl] = double2{0.0, 0.0};
+        s.hasgoal[sl] = 0;
+      }
+      continue;
+    }
     px[r] = L.agent_pos[2 * i];
     py[r] = L.agent_pos[2 * i + 1];
     vx[r] = L.agent_vel[2 * i];
     vy[r] = L.agent_vel[2 * i + 1];
-    fx[r] = fy[r] = sw[r] = 0.0;
     if (ok_[r]) {
       const int hg = L.agent_c[i].has_goal;
       s.pos[sl] = double2{px[r], py[r]};
@@ -804,7 +854,9 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         fy[r] += gf.y;
       }
   };
-  if constexpr (GROUPS) add_group_forces();
+  if constexpr (GROUPS) {
+    if (L.phase != SFW_PHASE_SUFFIX) add_group_forces();  // the class record's force already has them
+  }
 
   const int rows = A / 2;            // half ring; for even A the last row is half length
   const bool even = (A & 1) == 0;
@@ -816,7 +868,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   for (int r = 0; r < NS; ++r) hi_[r] = 16 * (sl_[r] - i_[r] + A);
   const int wrap = 16 * A;
 
-  for (int step = 0; step < S; ++step) {
+  for (int step = step_begin; step < step_end; ++step) {
     // This step's robot records (32 B per sample, contiguous) go from the K1 table straight to
     // LDS (global_load_lds_dwordx4: no VGPRs), in flight during the pair pass.  The waves of a
     // launch start together and run the same instruction stream, so a load issued where it is
@@ -824,9 +876,9 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     // at cfg2 before this, profiles/r01e).
     for (int c = 0; c < 2 * Gn; c += WAVE)  // 16 B per lane, 64 lanes per instruction
       if (c + lane < 2 * Gn) {
-        const char *src =
-            reinterpret_cast<const char *>(L.rstep + static_cast<int64_t>(step) * L.rstep_stride + first_local) +
-            16 * (c + lane);
+        const int64_t rsample = robot_sample_of_item(L, first_local + ((c + lane) >> 1));
+        const char *src = reinterpret_cast<const char *>(L.rstep + static_cast<int64_t>(step) * L.rstep_stride + rsample) +
+                          16 * ((c + lane) & 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(s.rsb) + 16 * c),
                                          16, 0, 0);
@@ -883,6 +935,21 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     if constexpr (GROUPS) add_group_forces();
   }
 
+  if (L.phase == SFW_PHASE_PREFIX) {  // leave the class records
+#pragma unroll
+    for (int r = 0; r < NS; ++r)
+      if (ok_[r] && g_[r] < Gn) {
+        const double2 p = s.pos[sl_[r]], v = s.vel[sl_[r]];
+        sfw_cls_agent c;
+        c.px = p.x; c.py = p.y; c.vx = v.x; c.vy = v.y;
+        c.fx = fx[r]; c.fy = fy[r]; c.sw = sw[r];
+        c.hasgoal = s.hasgoal[sl_[r]];
+        c.pad = 0;
+        L.cls_state[(first_local + g_[r]) * A + i_[r]] = c;
+      }
+    if (lane < Gn) L.cls_dead[first_local + lane] = s.dead[lane];
+    return;
+  }
   double sw_acc = 0.0;
 #pragma unroll
   for (int r = 0; r < NS; ++r) {
@@ -939,29 +1006,48 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
   const int64_t first_local = xcd_contiguous(blockIdx.x, gridDim.x);
   const sfm_consts<R> k = make_consts<R, true>(L);
   const double inv_O = L.k.inv_O;
-  if (!stage_wave<GROUPS, GROUPS>(L, s, lane, 1, 1, first_local)) return;
+  const int step_begin = L.phase == SFW_PHASE_SUFFIX ? L.step_split : 0;
+  const int step_end = L.phase == SFW_PHASE_PREFIX ? L.step_split : S;
+  if (!stage_wave<GROUPS, GROUPS>(L, s, lane, 1, 1, first_local)) {
+    if (L.phase == SFW_PHASE_SUFFIX) finish_wave(L, s, lane, 1, 1, A, first_local, 0.0);  // inherited contact
+    return;
+  }
+  const int64_t rsample = robot_sample_of_item(L, first_local);
 
-  for (int sl = lane; sl < A; sl += WAVE) {
-    const double px = L.agent_pos[2 * sl], py = L.agent_pos[2 * sl + 1];
-    const double vx = L.agent_vel[2 * sl], vy = L.agent_vel[2 * sl + 1];
-    const sfw_agent_const c = L.agent_c[sl];
-    s.pos[sl] = double2{px, py};
-    s.vel[sl] = double2{vx, vy};
-    s.hasgoal[sl] = c.has_goal;
-    s.swp[sl] = 0.0;
-    double fx = 0.0, fy = 0.0;
-    if (sl != 0) {
-      desired_force<R>(k, px, py, vx, vy, c.has_goal != 0, c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity, fx,
-                       fy);
-      if (O > 0) {
-        double ox, oy;
-        obstacle_force<R>(k, s.obs, O, inv_O, px, py, c.radius, ox, oy);
-        fx += ox;
-        fy += oy;
-      }
+  if (L.phase == SFW_PHASE_SUFFIX) {  // resume from the class record
+    const sfw_cls_agent *rec = L.cls_state + class_of_sample(L, first_local) * A;
+    for (int sl = lane; sl < A; sl += WAVE) {
+      const sfw_cls_agent c = rec[sl];
+      s.pos[sl] = double2{c.px, c.py};
+      s.vel[sl] = double2{c.vx, c.vy};
+      s.hasgoal[sl] = c.hasgoal;
+      s.swp[sl] = c.sw;
+      s.frc[sl] = double2{c.fx, c.fy};
+      s.frj[sl] = double2{0.0, 0.0};
     }
-    s.frc[sl] = double2{fx, fy};
-    s.frj[sl] = double2{0.0, 0.0};
+  } else {
+    for (int sl = lane; sl < A; sl += WAVE) {
+      const double px = L.agent_pos[2 * sl], py = L.agent_pos[2 * sl + 1];
+      const double vx = L.agent_vel[2 * sl], vy = L.agent_vel[2 * sl + 1];
+      const sfw_agent_const c = L.agent_c[sl];
+      s.pos[sl] = double2{px, py};
+      s.vel[sl] = double2{vx, vy};
+      s.hasgoal[sl] = c.has_goal;
+      s.swp[sl] = 0.0;
+      double fx = 0.0, fy = 0.0;
+      if (sl != 0) {
+        desired_force<R>(k, px, py, vx, vy, c.has_goal != 0, c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity,
+                         fx, fy);
+        if (O > 0) {
+          double ox, oy;
+          obstacle_force<R>(k, s.obs, O, inv_O, px, py, c.radius, ox, oy);
+          fx += ox;
+          fy += oy;
+        }
+      }
+      s.frc[sl] = double2{fx, fy};
+      s.frj[sl] = double2{0.0, 0.0};
+    }
   }
   __syncthreads();
   auto add_group_forces = [&]() {
@@ -985,13 +1071,15 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
       }
     __syncthreads();
   };
-  if constexpr (GROUPS) add_group_forces();
+  if constexpr (GROUPS) {
+    if (L.phase != SFW_PHASE_SUFFIX) add_group_forces();  // the class record's force already has them
+  }
 
   const int P = A * (A - 1) / 2;  // unordered pairs
   const int n_it = (P + WAVE - 1) / WAVE;
   const int robot_id = L.agent_c[0].id;
 
-  for (int step = 0; step < S; ++step) {
+  for (int step = step_begin; step < step_end; ++step) {
     const uint32_t *row = L.pair_tab;  // wave-uniform: scalar base + constant lane offset
     uint32_t next = n_it > 0 ? row[lane] : PAIR_NONE;
     for (int it = 0; it < n_it; ++it) {
@@ -1012,7 +1100,7 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
       }
     }
     __syncthreads();
-    const sfw_robot_step rs = L.rstep[static_cast<int64_t>(step) * L.rstep_stride + first_local];
+    const sfw_robot_step rs = L.rstep[static_cast<int64_t>(step) * L.rstep_stride + rsample];
     for (int sl = lane; sl < A; sl += WAVE) {
       const agent_k ak = GROUPS ? agent_k_lds(s, sl) : agent_k_global(L, sl);
       const double2 Fi = s.frc[sl], Fj = s.frj[sl];
@@ -1029,6 +1117,20 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
     __syncthreads();
     if (s.dead[0] != 0) break;
     if constexpr (GROUPS) add_group_forces();
+  }
+  if (L.phase == SFW_PHASE_PREFIX) {  // leave the class record
+    sfw_cls_agent *rec = L.cls_state + first_local * A;
+    for (int sl = lane; sl < A; sl += WAVE) {
+      const double2 p = s.pos[sl], v = s.vel[sl], f = s.frc[sl];
+      sfw_cls_agent c;
+      c.px = p.x; c.py = p.y; c.vx = v.x; c.vy = v.y;
+      c.fx = f.x; c.fy = f.y; c.sw = s.swp[sl];
+      c.hasgoal = s.hasgoal[sl];
+      c.pad = 0;
+      rec[sl] = c;
+    }
+    if (lane == 0) L.cls_dead[first_local] = s.dead[0];
+    return;
   }
   double sw_acc = 0.0;
   for (int sl = lane; sl < A; sl += WAVE) sw_acc += s.swp[sl];
@@ -1187,13 +1289,20 @@ void sfw_derive(sfw_launch &L) {
 
 static int flat_cap(int A) { return A <= 64 ? 64 : A <= 128 ? 128 : A <= 256 ? 256 : 0; }
 
-size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T) {
-  const wave_plan pl = plan_for(A, T);
+static size_t lds_bytes_for(const wave_plan &pl, int A, int O, int NG, int n_grp_mem) {
   if (pl.flat) {
     const int c = flat_cap(A);
     return lds_layout(nullptr, A, c > 0 ? c : A, A, 1, O, NG, n_grp_mem, NG > 0, true).bytes;
   }
   return lds_layout(nullptr, A, WAVE * pl.ns, pl.G * A, pl.G, O, NG, n_grp_mem, true, false).bytes;
+}
+
+// Largest LDS allocation any launch of a chunk of T samples may ask for (the prefix phase of the
+// shared-prefix rollout may pick the flat organisation where the chunk itself uses the other).
+size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T) {
+  const size_t a = lds_bytes_for(plan_for(A, T), A, O, NG, n_grp_mem);
+  const size_t b = A >= 2 ? lds_bytes_for(wave_plan{1, 0, true}, A, O, NG, n_grp_mem) : 0;
+  return a > b ? a : b;
 }
 
 int64_t sfw_pair_table_entries(int A) {
@@ -1245,9 +1354,13 @@ template <typename K> static hipError_t launch_social_as(K kernel, const sfw_lau
 }
 
 template <typename R> static hipError_t launch_social_typed(const sfw_launch &L, hipStream_t stream) {
-  const wave_plan pl = plan_for(L.A, L.chunk_count);
-  const unsigned grid = static_cast<unsigned>((L.chunk_count + pl.G - 1) / pl.G);
-  const size_t lds = sfw_social_lds_bytes(L.A, L.O, L.NG, L.n_grp_mem, L.chunk_count);
+  // The organisations are bit-identical and the class records of the shared-prefix rollout are
+  // organisation-neutral, so every launch picks its own by its item count (measured: forcing the
+  // flat form on an under-filled prefix phase at cfg2 — 2024 register-form waves — changes nothing).
+  const int64_t items = L.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L.n_cls) : L.chunk_count;
+  const wave_plan pl = plan_for(L.A, items);
+  const unsigned grid = static_cast<unsigned>((items + pl.G - 1) / pl.G);
+  const size_t lds = lds_bytes_for(pl, L.A, L.O, L.NG, L.n_grp_mem);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const bool groups = L.NG > 0;  // at least one agent carries a group id: kernels with the group pass
   if (pl.flat) {

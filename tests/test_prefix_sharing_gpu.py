@@ -1,0 +1,118 @@
+"""Shared-prefix rollout (csrc/sfw_device.h: sfw_cls_agent): the first P steps are simulated once
+per class of samples whose robot trajectories coincide under the acceleration limits.  It must not
+show in the results: costs, sentinels, selection and Trajectory point counts are BIT-identical to
+the unshared rollout, for every split step, kernel organisation, chunking and precision mode."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+
+from social_force_window_planner_amd import synthetic as syn
+from social_force_window_planner_amd._abi import SFW_PRECISION_F32, default_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _score(hip_mod, scene, params, prefix, budget_mb=None, goal_args=None, want_points=False):
+    """One grid call on a fresh handle created under SFW_PREFIX=<prefix> (read in sfw_create)."""
+    old = {k: os.environ.get(k) for k in ("SFW_PREFIX", "SFW_TABLE_BUDGET_MB")}
+    try:
+        os.environ["SFW_PREFIX"] = str(prefix)
+        if budget_mb is not None:
+            os.environ["SFW_TABLE_BUDGET_MB"] = str(budget_mb)
+        g = hip_mod.HipScorer(params)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    g.load_scene(scene)
+    costs, best = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, goal_args or scene.goal_args)
+    if want_points:
+        _, n = g.grid_points_batch(0, len(costs), scene.workload.n_steps)
+        return costs, best, n
+    return costs, best
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+
+
+def _params(w, **kw):
+    return default_params(sim_time=w.sim_time, sim_granularity=w.sim_granularity, **kw)
+
+
+@pytest.mark.parametrize("name,nv,nw,people", [("cfg2", 64, 64, 20), ("target", 64, 64, 50), ("cfg5", 16, 32, 100),
+                                                ("cfg2", 48, 32, 63)])
+def test_bit_identical_for_every_split(hip_mod, name, nv, nw, people):
+    """Register-resident (A = 21, 64) and flat (A = 51, 101) organisations; P = 1, automatic, deep."""
+    w = dataclasses.replace(syn.WORKLOADS[name], nv=nv, nw=nw, n_people=people)
+    scene = syn.make_scene(w)
+    p = _params(w)
+    ref, bref = _score(hip_mod, scene, p, 0)
+    assert (ref >= 0).sum() > 0
+    for prefix in (-1, 1, 7, w.n_steps - 1):
+        c, b = _score(hip_mod, scene, p, prefix)
+        assert _same(ref, c), f"SFW_PREFIX={prefix}: costs differ"
+        assert b == bref
+
+
+def test_matches_oracle_with_sharing_forced(oracle_mod, hip_mod):
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=12, nw=12, n_people=9, seed=31)
+    scene = syn.make_scene(w)
+    p = _params(w)
+    o = oracle_mod.OracleScorer(_params(w))
+    o.load_scene(scene)
+    oc, ob = o.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args, n_threads=16)
+    for prefix in (0, 12):
+        gc, gb = _score(hip_mod, scene, p, prefix)
+        v = oc >= 0
+        assert np.array_equal(oc < 0, gc < 0) and np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= 1e-9
+        assert gb["index"] == ob["index"] and gb["n_valid"] == ob["n_valid"]
+
+
+def test_contacts_inside_the_prefix_and_points(hip_mod):
+    """Dense crowd from 0.8 m: many classes end in a pedestrian contact inside the shared steps; the
+    members inherit the verdict and the contact step (Trajectory point counts)."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg4"], nv=16, nw=16, n_people=120, people_r_in=0.8, seed=4)
+    scene = syn.make_scene(w)
+    p = _params(w)
+    ref, bref, nref = _score(hip_mod, scene, p, 0, want_points=True)
+    assert (ref == -1.0).sum() > 0
+    for prefix in (3, 20):
+        c, b, n = _score(hip_mod, scene, p, prefix, want_points=True)
+        assert _same(ref, c) and b == bref and np.array_equal(n, nref)
+
+
+def test_zero_sample_as_class_representative(hip_mod):
+    """A decelerating robot with tight acceleration limits: every sample whose targets lie below the
+    reachable window shares its first steps with the never-scored (0,0) sample, which is the first
+    member (= the representative) of that class; a cluttered costmap rejects part of the grid."""
+    w = dataclasses.replace(syn.WORKLOADS["ref5x9"], n_people=12, n_discs=25, seed=77)
+    scene = syn.make_scene(w)
+    lin, ang = syn.generalised_sampler(9, 9)  # contains (0, 0)
+    scene = dataclasses.replace(scene, linvels=lin, angvels=ang, robot_state=(0.0, 0.0, 0.3, 0.5, 0.0, 0.375))
+    p = _params(w)
+    ga = (0.2, 0.0, 0.3, 2.0, 0.5)  # 5 mm/s and 7.5 mrad/s per step
+    ref, bref = _score(hip_mod, scene, p, 0, goal_args=ga)
+    assert ref[0] == -2.0
+    for prefix in (1, 5, 30):
+        c, b = _score(hip_mod, scene, p, prefix, goal_args=ga)
+        assert _same(ref, c) and b == bref
+
+
+def test_chunked_launch_groups_obstacles_and_f32(hip_mod):
+    """Several chunks of whole rows (1 MiB table budget), laser points and a group, both precisions."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=40, nw=40, n_people=12, n_obstacles=8, seed=19)
+    scene = syn.make_scene(w)
+    for i in (2, 3, 4):
+        scene.agents[i].group_id = 7
+    for prec in ({}, {"precision": SFW_PRECISION_F32}):
+        p = _params(w, **prec)
+        ref, bref = _score(hip_mod, scene, p, 0)
+        for prefix, budget in ((6, None), (6, 1), (-1, 1)):
+            c, b = _score(hip_mod, scene, p, prefix, budget_mb=budget)
+            assert _same(ref, c), (prec, prefix, budget)
+            assert b == bref
