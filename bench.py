@@ -133,6 +133,7 @@ class GridJob:
         zero = int(np.any(self.lin == 0.0) and np.any(self.ang == 0.0))
         self.n_scored = self.n_local - zero  # the (0,0) sample is never scored (ref :349-352)
         self.scorer.stage(self.scene.robot_state, self.lin, self.ang, self.scene.goal_args, self.index_base)
+        self.plan = self.scorer.plan_info()
 
     def step(self):
         self.scorer.launch()
@@ -234,6 +235,13 @@ def roofline_for(job, k2_ms, precision):
                          "(the K1->K2 robot-step table; algorithmic bytes are in roofline.hbm)") if tr else None,
         "flops_per_trajectory": flops_traj,
         "kernel_ms": k2_ms,
+        "launches_per_step": job.plan["chunks"] * (2 if job.plan["split_step"] > 0 else 1),
+        "shared_prefix": ({"split_step": job.plan["split_step"], "classes": job.plan["classes"],
+                           "samples": job.plan["samples"],
+                           "note": "steps [0, split_step) are simulated once per class of samples whose robot "
+                                   "trajectories coincide under the acceleration limits (bit-identical costs); "
+                                   "kernel_ms is the sum of the prefix and the suffix launch, `achieved` still "
+                                   "prices the full algorithmic work"} if job.plan["split_step"] > 0 else None),
         "note": "algorithmic flops per SURVEY.md §8d (48 per ordered pair incl. exp/atan2/sqrt as 1 op each); "
                 "non-MFMA vector peak for the dtype",
         "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,

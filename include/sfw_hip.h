@@ -216,6 +216,21 @@ int sfw_grid_sync(sfw_handle h);
 /* D2H of the cost vector (nullable) and the local selection (nullable). */
 int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out,
                    sfw_best_key *key_out);
+/* How the staged grid will be launched.  split_step > 0: the shared-prefix
+ * rollout is in use — under the acceleration limits (sfw_planner.hpp:457-463)
+ * the robot's first split_step steps are bit-identical for all samples of a
+ * class (same clipped linear x angular velocity sequences), so those steps are
+ * simulated once per class (classes = sum over chunks of row classes x column
+ * classes) and every sample resumes from its class's state.  Costs are
+ * bit-identical to the plain rollout; SFW_PREFIX=0 in the environment of
+ * sfw_create switches it off. */
+typedef struct sfw_plan_info {
+  int32_t split_step; /* 0: plain rollout                                   */
+  int32_t chunks;     /* launches of the K1->K2 table (SFW_TABLE_BUDGET_MB) */
+  int64_t classes;    /* items of the prefix phase                          */
+  int64_t samples;    /* nv * nw                                            */
+} sfw_plan_info;
+int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out);
 /* Per-kernel HIP events around the kernels of sfw_grid_launch, off by default
  * (a control cycle is latency-bound; four event records cost as much as a
  * kernel).  Measurement tooling (bench.py) switches them on. */

@@ -130,6 +130,13 @@ class SfwBestKey(C.Structure):
         return (self.cost, self.neg_linvel, self.abs_angvel, self.neg_index)
 
 
+class SfwPlanInfo(C.Structure):
+    _fields_ = [("split_step", C.c_int32), ("chunks", C.c_int32), ("classes", C.c_int64), ("samples", C.c_int64)]
+
+    def as_dict(self):
+        return {"split_step": self.split_step, "chunks": self.chunks, "classes": self.classes, "samples": self.samples}
+
+
 # Every symbol include/sfw_hip.h declares (checked by tests/test_abi.py).
 EXPORTED_SYMBOLS = (
     "sfw_params_default",
@@ -147,6 +154,7 @@ EXPORTED_SYMBOLS = (
     "sfw_grid_launch",
     "sfw_grid_sync",
     "sfw_grid_fetch",
+    "sfw_grid_plan_info",
     "sfw_set_timing",
     "sfw_last_launch_ms",
     "sfw_grid_points",

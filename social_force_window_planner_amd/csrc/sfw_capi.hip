@@ -768,6 +768,25 @@ int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp, doubl
   return SFW_OK;
 }
 
+int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out) {
+  if (!h || !out) return SFW_ERR_INVALID_ARG;
+  if (!h->staged) return fail(h, SFW_ERR_STATE, "grid_plan_info before grid_stage");
+  const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
+  out->split_step = h->prefix_P;
+  out->samples = T;
+  out->classes = 0;
+  if (h->prefix_P > 0) {
+    out->chunks = static_cast<int32_t>(h->prefix_chunks.size());
+    for (const auto &c : h->prefix_chunks) out->classes += static_cast<int64_t>(c.n_row_cls) * h->prefix_ncol;
+  } else {
+    const int S = num_steps_of(h->params);
+    int64_t chunk = static_cast<int64_t>(std::min(h->rstep.cap, std::min(h->frame.cap, h->fcode.cap)) / S);
+    if (chunk > T) chunk = T;
+    out->chunks = chunk > 0 ? static_cast<int32_t>((T + chunk - 1) / chunk) : 0;
+  }
+  return SFW_OK;
+}
+
 int sfw_set_timing(sfw_handle h, int32_t enabled) {
   if (!h) return SFW_ERR_INVALID_ARG;
   h->timing = enabled != 0;

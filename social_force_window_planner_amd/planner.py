@@ -22,6 +22,7 @@ from ._abi import (
     SfwGoalArgs,
     SfwParams,
     SfwRobotState,
+    SfwPlanInfo,
     default_params,
 )
 
@@ -82,6 +83,7 @@ def lib():
         L.sfw_grid_launch.argtypes = [vp]
         L.sfw_grid_sync.argtypes = [vp]
         L.sfw_grid_fetch.argtypes = [vp, vp, C.POINTER(SfwBest), C.POINTER(SfwBestKey)]
+        L.sfw_grid_plan_info.argtypes = [vp, C.POINTER(SfwPlanInfo)]
         L.sfw_set_timing.argtypes = [vp, C.c_int32]
         L.sfw_last_launch_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
         L.sfw_grid_points.argtypes = [vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32)]
@@ -201,6 +203,12 @@ class HipScorer:
         self._check(lib().sfw_grid_fetch(self._h, costs.ctypes.data if want_costs else None, C.byref(best),
                                          C.byref(key)), "sfw_grid_fetch")
         return costs, best.as_dict(), key.as_tuple()
+
+    def plan_info(self):
+        """How the staged grid will be launched (shared-prefix split step, classes, chunks)."""
+        info = SfwPlanInfo()
+        self._check(lib().sfw_grid_plan_info(self._h, C.byref(info)), "sfw_grid_plan_info")
+        return info.as_dict()
 
     def set_timing(self, enabled=True):
         """Per-kernel HIP events for last_launch_ms (off by default: latency path)."""

@@ -1,5 +1,6 @@
 """Build profiles/r01_traffic.json from the FETCH_SIZE/WRITE_SIZE summaries written by tools/profile.sh.
-usage: traffic_json.py <workload>=<traffic.txt> ... > profiles/r01_traffic.json"""
+usage: traffic_json.py <workload>=<traffic.txt>[:<K2 launches per step>] ... > profiles/r01_traffic.json
+(the summaries hold means per dispatch; with the shared-prefix rollout K2 is two dispatches per step)"""
 import json
 import re
 import sys
@@ -7,6 +8,10 @@ import sys
 out = {}
 for arg in sys.argv[1:]:
     name, path = arg.split("=")
+    per_step = 1
+    if ":" in path:
+        path, n = path.rsplit(":", 1)
+        per_step = int(n)
     kernels, cur = {}, None
     for line in open(path):
         m = re.match(r"== (\S.*?)\s+dispatches=", line)
@@ -21,8 +26,10 @@ for arg in sys.argv[1:]:
     out[name] = {
         "kernels": kernels,
         "k2": k2,
-        "k2_bytes": kernels[k2]["fetch_bytes"] + kernels[k2]["write_bytes"],
-        "all_kernels_bytes": sum(v.get("fetch_bytes", 0) + v.get("write_bytes", 0) for v in kernels.values()),
+        "k2_launches_per_step": per_step,
+        "k2_bytes": per_step * (kernels[k2]["fetch_bytes"] + kernels[k2]["write_bytes"]),
+        "all_kernels_bytes": sum((per_step if k == k2 else 1) * (v.get("fetch_bytes", 0) + v.get("write_bytes", 0))
+                                 for k, v in kernels.items()),
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile.sh), KB x 1024, "
                   "mean per dispatch; 32-byte-per-lane records, so the gfx950 half-reporting of 16 B/lane streams "
                   "does not apply (K2 fetch == K1->K2 robot-step table size)",
