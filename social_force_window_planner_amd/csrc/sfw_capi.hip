@@ -239,24 +239,35 @@ double new_velocity_host(double vg, double vi, double a_max, double dt) {
 
 // Classes of the samples' velocity sequences after 1..max_p steps: cls[p-1][i] is the class of
 // sample value i when the first p velocities are compared, counts[p-1] the number of classes.
+// Stops early once every value is its own class (nothing left to share from there on): cls/counts
+// may hold fewer than max_p levels.  Runs on the control-cycle path: sort-based, no allocation per step.
 void velocity_classes(const std::vector<double> &targets, double v0, double a_max, double dt, int max_p,
                       std::vector<std::vector<int32_t>> &cls, std::vector<int32_t> &counts) {
+  struct key { int32_t cls; int32_t idx; uint64_t bits; };
   const size_t n = targets.size();
   std::vector<double> v(n, v0);
   std::vector<int32_t> cur(n, 0);
+  std::vector<key> keys(n);
   cls.clear();
   counts.clear();
   for (int p = 0; p < max_p; ++p) {
-    std::map<std::pair<int32_t, uint64_t>, int32_t> ids;
     for (size_t i = 0; i < n; ++i) {
       v[i] = new_velocity_host(targets[i], v[i], a_max, dt);
-      uint64_t bits;
-      std::memcpy(&bits, &v[i], sizeof(bits));
-      auto it = ids.emplace(std::make_pair(cur[i], bits), static_cast<int32_t>(ids.size())).first;
-      cur[i] = it->second;
+      keys[i].cls = cur[i];
+      keys[i].idx = static_cast<int32_t>(i);
+      std::memcpy(&keys[i].bits, &v[i], sizeof(uint64_t));
+    }
+    std::sort(keys.begin(), keys.end(), [](const key &a, const key &b) {
+      return a.cls != b.cls ? a.cls < b.cls : a.bits != b.bits ? a.bits < b.bits : a.idx < b.idx;
+    });
+    int32_t id = -1;
+    for (size_t k = 0; k < n; ++k) {
+      if (k == 0 || keys[k].cls != keys[k - 1].cls || keys[k].bits != keys[k - 1].bits) ++id;
+      cur[static_cast<size_t>(keys[k].idx)] = id;
     }
     cls.push_back(cur);
-    counts.push_back(static_cast<int32_t>(ids.size()));
+    counts.push_back(id + 1);
+    if (static_cast<size_t>(id + 1) == n) break;
   }
 }
 
@@ -273,10 +284,16 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   std::vector<int32_t> nr, nc;
   velocity_classes(h->h_lin, h->rs.vx, h->ga.acc_x, dt, max_p, rc, nr);
   velocity_classes(h->h_ang, h->rs.vtheta, h->ga.acc_theta, dt, max_p, cc, nc);
+  // a level past the last computed one has every value in its own class
+  auto level = [](const std::vector<std::vector<int32_t>> &c, int p) -> const std::vector<int32_t> & {
+    return c[std::min<size_t>(static_cast<size_t>(p), c.size()) - 1];
+  };
+  auto count_at = [](const std::vector<int32_t> &n, int p) { return n[std::min<size_t>(static_cast<size_t>(p), n.size()) - 1]; };
   int best_p = 0;
   double best_saved = 0.0;
-  for (int p = 1; p <= max_p; ++p) {
-    const double saved = (static_cast<double>(T) - static_cast<double>(nr[p - 1]) * nc[p - 1]) * p;
+  const int last_p = std::min<int>(max_p, static_cast<int>(std::max(nr.size(), nc.size())));
+  for (int p = 1; p <= last_p; ++p) {
+    const double saved = (static_cast<double>(T) - static_cast<double>(count_at(nr, p)) * count_at(nc, p)) * p;
     if (saved > best_saved) { best_saved = saved; best_p = p; }
   }
   if (h->prefix_env > 0) best_p = std::min(h->prefix_env, max_p);
@@ -285,8 +302,8 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   // chunks of whole rows
   int64_t rows_per_chunk = chunk / h->nw;
   if (rows_per_chunk < 1) return SFW_OK;  // a single row does not fit the table budget: no sharing
-  const std::vector<int32_t> &row_cls_g = rc[best_p - 1], &col_cls = cc[best_p - 1];
-  const int ncol = nc[best_p - 1];
+  const std::vector<int32_t> &row_cls_g = level(rc, best_p), &col_cls = level(cc, best_p);
+  const int ncol = count_at(nc, best_p);
   std::vector<int32_t> ints;  // col_cls | col_rep | per chunk: row_cls (local) | row_rep (local rows)
   h->prefix_o_col_cls = ints.size();
   ints.insert(ints.end(), col_cls.begin(), col_cls.end());
@@ -328,7 +345,7 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   SFW_HIP(h, h->cls_state.reserve(static_cast<size_t>(max_cls) * h->st_A));
   if (std::getenv("SFW_DEBUG_PLAN"))
     std::fprintf(stderr, "[sfw] shared prefix: P=%d of S=%d, %d x %d classes of %d x %d samples, %zu chunk(s)\n", best_p, S,
-                 nr[best_p - 1], ncol, h->nv, h->nw, h->prefix_chunks.size());
+                 count_at(nr, best_p), ncol, h->nv, h->nw, h->prefix_chunks.size());
   h->prefix_P = best_p;
   h->prefix_S = S;
   h->prefix_ncol = ncol;
