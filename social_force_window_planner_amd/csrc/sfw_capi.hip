@@ -85,6 +85,8 @@ struct sfw_planner_s {
   sfw_params params;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;  // K1b + K1c beside the shared-prefix phase of K2
+  hipEvent_t ev_poses = nullptr, ev_side = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> chunk_ev;  // 3 per chunk of a multi-chunk launch: K1 start, K1 end/K2 start, K2 end
   int n_chunks = 1;
@@ -460,9 +462,15 @@ int launch_common(sfw_handle h) {
     sfw_launch L;
     fill_launch(h, L, b, n, chunk);
     if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c], h->stream));
-    SFW_HIP(h, sfw_launch_rollout(L, h->stream));
-    if (timing) SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
     if (prefix) {
+      // K1a -> { K2 prefix phase on the main stream  ||  K1b + K1c on the side stream } -> K2 suffix phase.
+      // The prefix phase needs the robot-step table only and under-fills the GPU (one item per class).
+      SFW_HIP(h, sfw_launch_rollout_poses(L, h->stream));
+      SFW_HIP(h, hipEventRecord(h->ev_poses, h->stream));
+      SFW_HIP(h, hipStreamWaitEvent(h->side, h->ev_poses, 0));
+      SFW_HIP(h, sfw_launch_rollout_costmap(L, h->side));
+      SFW_HIP(h, hipEventRecord(h->ev_side, h->side));
+      if (timing) SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
       const sfw_planner_s::chunk_classes &cc = h->prefix_chunks[static_cast<size_t>(c)];
       L.step_split = h->prefix_P;
       L.n_col_cls = h->prefix_ncol;
@@ -475,9 +483,12 @@ int launch_common(sfw_handle h) {
       L.cls_dead = h->cls_dead.p;
       L.phase = SFW_PHASE_PREFIX;
       SFW_HIP(h, sfw_launch_social(L, h->stream));
+      SFW_HIP(h, hipStreamWaitEvent(h->stream, h->ev_side, 0));
       L.phase = SFW_PHASE_SUFFIX;
       SFW_HIP(h, sfw_launch_social(L, h->stream));
     } else {
+      SFW_HIP(h, sfw_launch_rollout(L, h->stream));
+      if (timing) SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
       SFW_HIP(h, sfw_launch_social(L, h->stream));
     }
     if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c + 2], h->stream));
@@ -570,6 +581,9 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
   }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_poses, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming);
   for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
   if (e != hipSuccess) {
     sfw_destroy(h);
@@ -583,6 +597,7 @@ int sfw_destroy(sfw_handle h) {
   if (!h) return SFW_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->side) (void)hipStreamSynchronize(h->side);
   h->cells.release();
   h->world.release();
   h->pair_tab.release();
@@ -607,6 +622,9 @@ int sfw_destroy(sfw_handle h) {
     if (e) (void)hipEventDestroy(e);
   for (auto &e : h->chunk_ev)
     if (e) (void)hipEventDestroy(e);
+  if (h->ev_poses) (void)hipEventDestroy(h->ev_poses);
+  if (h->ev_side) (void)hipEventDestroy(h->ev_side);
+  if (h->side) (void)hipStreamDestroy(h->side);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return SFW_OK;

@@ -135,7 +135,11 @@ struct sfw_sel {
 void sfw_derive(sfw_launch &L);
 
 // Launchers (sfw_kernels.hip).  All enqueue on `stream` and return hipError_t.
-hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream);
+hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream);  // = poses, then costmap
+// The two halves of K1: the social kernel's prefix phase needs only the first (the robot-step
+// table), so the second can run beside it on another stream.
+hipError_t sfw_launch_rollout_poses(const sfw_launch &L, hipStream_t stream);
+hipError_t sfw_launch_rollout_costmap(const sfw_launch &L, hipStream_t stream);
 hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream);
 // Reduces costs[0..T) to one sfw_sel at *out (device memory).  partials must
 // hold >= sfw_argmin_partials(T) records.

@@ -1317,17 +1317,24 @@ hipError_t sfw_launch_pair_table(uint32_t *tab, int A, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream) {
+bool sfw_rollout_is_fused(const sfw_launch &L) { return L.chunk_count <= 2048 && L.S <= K1_SMALL_MAX_STEPS; }
+
+// K1a alone (pose integration + robot-step table), or the fused small-grid K1.
+hipError_t sfw_launch_rollout_poses(const sfw_launch &L, hipStream_t stream) {
   if (L.chunk_count <= 0) return hipSuccess;
-  if (L.chunk_count <= 2048 && L.S <= K1_SMALL_MAX_STEPS) {  // latency path: one launch
+  if (sfw_rollout_is_fused(L)) {  // latency path: one launch does all of K1
     hipLaunchKernelGGL(sfw_rollout_small_kernel, dim3(static_cast<unsigned>(L.chunk_count)), dim3(64), 0, stream, L);
     return hipGetLastError();
   }
-  {
-    const int block = 64;  // latency-bound serial rollout: spread the waves over all CUs
-    const unsigned grid = static_cast<unsigned>((L.chunk_count + block - 1) / block);
-    hipLaunchKernelGGL(sfw_rollout_kernel, dim3(grid), dim3(block), 0, stream, L);
-  }
+  const int block = 64;  // latency-bound serial rollout: spread the waves over all CUs
+  const unsigned grid = static_cast<unsigned>((L.chunk_count + block - 1) / block);
+  hipLaunchKernelGGL(sfw_rollout_kernel, dim3(grid), dim3(block), 0, stream, L);
+  return hipGetLastError();
+}
+
+// K1b + K1c (footprint checks, costmap scan); nothing to do after the fused K1.
+hipError_t sfw_launch_rollout_costmap(const sfw_launch &L, hipStream_t stream) {
+  if (L.chunk_count <= 0 || sfw_rollout_is_fused(L)) return hipSuccess;
   {
     const int block = 256;
     const int64_t n = L.chunk_count * L.S;
@@ -1340,6 +1347,11 @@ hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream) {
     hipLaunchKernelGGL(sfw_costmap_scan_kernel, dim3(grid), dim3(block), 0, stream, L);
   }
   return hipGetLastError();
+}
+
+hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream) {
+  hipError_t e = sfw_launch_rollout_poses(L, stream);
+  return e != hipSuccess ? e : sfw_launch_rollout_costmap(L, stream);
 }
 
 template <typename K> static hipError_t launch_social_as(K kernel, const sfw_launch &L, int G, unsigned grid,
