@@ -275,12 +275,81 @@ __global__ void __launch_bounds__(256) sfw_costmap_scan_kernel(const sfw_launch 
 constexpr int K1_SMALL_MAX_STEPS = 512;
 __global__ void __launch_bounds__(64) sfw_rollout_small_kernel(const sfw_launch L) {
   __shared__ sfw_pose_frame fr[K1_SMALL_MAX_STEPS];
+  __shared__ double th[K1_SMALL_MAX_STEPS], vxs[K1_SMALL_MAX_STEPS], vys[K1_SMALL_MAX_STEPS];
+  __shared__ double2 cs[K1_SMALL_MAX_STEPS], cs2[K1_SMALL_MAX_STEPS];
   __shared__ int16_t code[K1_SMALL_MAX_STEPS];
-  __shared__ int scored;
   const int64_t local = blockIdx.x;
   const int64_t t = L.chunk_begin + local;
   const int S = L.S;
-  if (threadIdx.x == 0) scored = rollout_sample(L, local, [&](int i, const sfw_pose_frame &f) { fr[i] = f; }) ? 1 : 0;
+  const int iv = static_cast<int>(t / L.nw), iw = static_cast<int>(t % L.nw);
+  const double vx_samp = L.linvels[iv], vth_samp = L.angvels[iw], vy_samp = L.vy_samp;
+  const bool scored = !(L.skip_zero_sample && vx_samp == 0.0 && vth_samp == 0.0);
+  const double dt = L.dt;
+  // rollout_sample's recurrence, split so that its only expensive part — one sincos per step, i.e.
+  // S dependent ~1000-cycle calls on one lane — runs on the block's 64 lanes at once: the velocity
+  // and heading recurrences do not depend on the sines, the position recurrence only adds them up.
+  // Same operations on the same values in the same order as the one-thread-per-sample K1a.
+  double th_i = L.rs.theta;
+  if (threadIdx.x == 0) {  // stage 1: velocities and headings, a few flops per step
+    if (!scored) {
+      L.status[t] = SFW_ST_SKIPPED;
+      L.costs[t] = SFW_COST_SKIPPED;
+    } else {
+      L.status[t] = SFW_ST_VALID;  // the costmap scan downgrades it if a step is illegal
+    }
+    if (L.coll_step) L.coll_step[t] = -1;
+    double vx_i = L.rs.vx, vy_i = L.rs.vy, vth_i = L.rs.vtheta;
+    for (int i = 0; i < S; ++i) {
+      vx_i = new_velocity(vx_samp, vx_i, L.ga.acc_x, dt);   // ref :581-583
+      vy_i = new_velocity(vy_samp, vy_i, L.ga.acc_y, dt);
+      vth_i = new_velocity(vth_samp, vth_i, L.ga.acc_theta, dt);
+      th[i] = th_i;  // heading before this step's update: ref :586-588 integrate with the old theta
+      vxs[i] = vx_i;
+      vys[i] = vy_i;
+      th_i = th_i + vth_i * dt;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {  // stage 2: the sines, one step per lane
+    double s, c, c2 = 0.0, s2 = 0.0;
+    sincos(th[i], &s, &c);
+    if (vys[i] != 0.0) sincos(M_PI_2 + th[i], &s2, &c2);  // holonomic term, 0 for the grid
+    cs[i] = double2{c, s};
+    cs2[i] = double2{c2, s2};
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // stage 3: positions, robot-step records, pedestrian-free cost terms
+    double x_i = L.rs.x, y_i = L.rs.y, vx_i = L.rs.vx;
+    for (int i = 0; i < S; ++i) {
+      const double2 a = cs[i], b = cs2[i];
+      sfw_pose_frame f;
+      f.x = x_i; f.y = y_i; f.c = a.x; f.s = a.y;
+      fr[i] = f;
+      if (L.points) {                                       // ref :578
+        double *pt = L.points + (local * S + i) * 3;
+        pt[0] = x_i;
+        pt[1] = y_i;
+        pt[2] = th[i];
+      }
+      vx_i = vxs[i];
+      const double vy_i = vys[i];
+      const double xn = x_i + (vx_i * a.x + vy_i * b.x) * dt;  // ref :586-588
+      const double yn = y_i + (vx_i * a.y + vy_i * b.y) * dt;
+      x_i = xn;
+      y_i = yn;
+      sfw_robot_step r;
+      r.x = x_i; r.y = y_i; r.vx = vx_i; r.vy = vy_i;
+      L.rstep[static_cast<int64_t>(i) * L.rstep_stride + local] = r;
+    }
+    // ref :643-666 without the costmap and social terms (left-to-right sum order kept)
+    const double dx = L.ga.wpx - x_i, dy = L.ga.wpy - y_i;
+    const double d = dx * dx + dy * dy;
+    double ang = atan2(dy, dx) - th_i;
+    ang = normalize_angle_f(static_cast<float>(ang), static_cast<float>(-M_PI), static_cast<float>(M_PI));
+    ang = fabs(ang) / M_PI;
+    const double vel = fabs(L.p.max_vel_x - vx_i) / L.p.max_vel_x;
+    L.base_cost[t] = L.p.vel_weight * vel + L.p.distance_weight * d + L.p.angle_weight * ang;
+  }
   __syncthreads();
   if (!scored) {
     if (threadIdx.x == 0 && L.n_points) L.n_points[local] = 0;
