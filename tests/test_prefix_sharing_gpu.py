@@ -116,3 +116,29 @@ def test_chunked_launch_groups_obstacles_and_f32(hip_mod):
             c, b = _score(hip_mod, scene, p, prefix, budget_mb=budget)
             assert _same(ref, c), (prec, prefix, budget)
             assert b == bref
+
+
+def test_plan_info_reports_the_split(hip_mod):
+    """sfw_grid_plan_info: the automatic plan shares a prefix on a GPU-filling grid under the
+    reference's acceleration limits and not on a 5 x 9 control-cycle grid; classes <= samples."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=64, nw=64)
+    scene = syn.make_scene(w)
+    g = hip_mod.HipScorer(_params(w))
+    g.load_scene(scene)
+    g.stage(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    info = g.plan_info()
+    assert info["samples"] == 4096 and info["chunks"] == 1
+    assert 1 <= info["split_step"] < w.n_steps and 0 < info["classes"] < info["samples"]
+    small = syn.make_scene("ref5x9")
+    g.load_scene(small)
+    g.stage(small.robot_state, small.linvels, small.angvels, small.goal_args)
+    assert g.plan_info() == {"split_step": 0, "chunks": 1, "classes": 0, "samples": 45}
+    # targets far outside the window reachable in the horizon: every sample shares every step but the last
+    lin = np.linspace(5.0, 6.0, 64)
+    ang = np.linspace(3.0, 4.0, 64)
+    g.load_scene(scene)
+    g.stage(scene.robot_state, lin, ang, scene.goal_args)
+    info = g.plan_info()
+    assert info["split_step"] == w.n_steps - 1 and info["classes"] == 1
+    c, b = g.score_grid(scene.robot_state, lin, ang, scene.goal_args)
+    assert np.all(c == c[0]) or (c < 0).any()  # one trajectory, 4096 times (or all rejected alike)
