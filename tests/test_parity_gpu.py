@@ -420,3 +420,20 @@ def test_group_forces(oracle_mod, hip_mod, n_people, seed):
     o.load_scene(scene)
     oc_plain, _ = o.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args, n_threads=8)
     assert not np.allclose(oc0, oc_plain, rtol=1e-6)
+
+
+def test_long_horizon_uses_the_three_kernel_rollout(oracle_mod, hip_mod):
+    """600 steps > the fused small-grid K1's LDS capacity (512): a 3 x 4 grid goes through K1a/K1b/K1c."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=3, nw=4, n_people=4, sim_time=6.0, sim_granularity=0.01, seed=23)
+    assert w.n_steps == 600
+    _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w, n_threads=12)
+    assert (oc >= 0).sum() > 0
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+def test_single_sample_and_single_step(oracle_mod, hip_mod):
+    """nv = nw = 1 and S = 1: the smallest launch of every kernel."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=1, nw=1, n_people=3, sim_time=0.025, seed=24)
+    assert w.n_steps == 1
+    _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w, n_threads=1)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
