@@ -46,12 +46,24 @@ constexpr int WAVE = 64;
 // last ulp matter, SURVEY.md §7 "discrete thresholds").
 #pragma clang fp contract(off)
 
-__device__ __forceinline__ bool world_to_map(const sfw_launch &L, double wx, double wy, unsigned &mx,
+// (unsigned)(a / res) for a >= 0, bit-for-bit the IEEE division + truncation of
+// nav2_costmap_2d::Costmap2D::worldToMap (Foxy), without paying for the
+// ~14-instruction division 34 times per pose: a * (1/res) is within a few ulp of the quotient, so the
+// truncations can only differ when the product lies within 1e-9 of an integer — then, and only then,
+// the lane takes the exact division (grid-aligned coordinates; rare, and still exact).
+__device__ __forceinline__ unsigned cell_index(double a, double res, double inv_res) {
+  const double q = a * inv_res;
+  const double m = __builtin_trunc(q);
+  const double d = q - m;
+  if (d < 1e-9 || d > 1.0 - 1e-9) return static_cast<unsigned>(a / res);
+  return static_cast<unsigned>(m);
+}
+
+__device__ __forceinline__ bool world_to_map(const sfw_launch &L, double inv_res, double wx, double wy, unsigned &mx,
                                              unsigned &my) {
-  // nav2_costmap_2d::Costmap2D::worldToMap (Foxy), SURVEY.md Appendix C
   if (wx < L.origin_x || wy < L.origin_y) return false;
-  mx = static_cast<unsigned>((wx - L.origin_x) / L.resolution);
-  my = static_cast<unsigned>((wy - L.origin_y) / L.resolution);
+  mx = cell_index(wx - L.origin_x, L.resolution, inv_res);
+  my = cell_index(wy - L.origin_y, L.resolution, inv_res);
   return mx < L.size_x && my < L.size_y;
 }
 
@@ -60,35 +72,37 @@ __device__ __forceinline__ int point_code(const sfw_launch &L, int x, int y) {
   return L.cells[static_cast<size_t>(y) * L.size_x + static_cast<size_t>(x)];
 }
 
-// Bresenham walk of one footprint edge (reference line_iterator.hpp:39-97,
-// src/costmap_model.cpp:95-110).  Returns the max cell cost, or -1 / -2 at the
-// first lethal / unknown cell.
-__device__ double line_cost(const sfw_launch &L, int x0, int y0, int x1, int y1) {
-  const int adx = abs(x1 - x0), ady = abs(y1 - y0);
-  const int sx = (x1 >= x0) ? 1 : -1, sy = (y1 >= y0) ? 1 : -1;
+// Bresenham walk of one footprint edge (reference line_iterator.hpp:39-97, src/costmap_model.cpp:95-110):
+// the largest cell value on the edge.  The reference stops at the first lethal (254 -> -1) or unknown
+// (255 -> -2) cell; a pose with such a cell on an edge is illegal whichever code it gets (ref :555-573
+// reject footprint_cost >= 254 and < 0 alike), so the walk is branch-free and the caller classifies the
+// maximum.  One linear cell index, major/minor steps in index units.
+__device__ __forceinline__ int line_max(const sfw_launch &L, int x0, int y0, int x1, int y1) {
+  const int dx = x1 - x0, dy = y1 - y0;
+  const int adx = abs(dx), ady = abs(dy);
+  const int stride = static_cast<int>(L.size_x);
+  const int sx = (dx >= 0) ? 1 : -1, sy = (dy >= 0) ? stride : -stride;
   const bool x_major = adx >= ady;
-  const int den = x_major ? adx : ady;
-  const int add = x_major ? ady : adx;
-  int num = den / 2, x = x0, y = y0, best = 0;
+  const int den = x_major ? adx : ady, add = x_major ? ady : adx;
+  const int dmaj = x_major ? sx : sy, dmin = x_major ? sy : sx;
+  int num = den / 2;
+  unsigned idx = static_cast<unsigned>(y0 * stride + x0);
+  int best = 0;
   for (int n = 0; n <= den; ++n) {
-    const int c = point_code(L, x, y);
-    if (c == 255) return -2.0;
-    if (c == 254) return -1.0;
-    best = max(best, c);
+    best = max(best, static_cast<int>(L.cells[idx]));
     num += add;
-    if (num >= den) {
-      num -= den;
-      if (x_major) y += sy; else x += sx;
-    }
-    if (x_major) x += sx; else y += sy;
+    const bool wrap = num >= den;
+    num -= wrap ? den : 0;
+    idx += static_cast<unsigned>(dmaj + (wrap ? dmin : 0));
   }
-  return static_cast<double>(best);
+  return best;
 }
 
 // reference world_model.hpp:45-75 + src/costmap_model.cpp:21-92; c,s = cos/sin(theta)
 __device__ double footprint_cost(const sfw_launch &L, double x, double y, double c, double s) {
+  const double inv_res = 1.0 / L.resolution;
   unsigned cx, cy;
-  if (!world_to_map(L, x, y, cx, cy)) return -3.0;
+  if (!world_to_map(L, inv_res, x, y, cx, cy)) return -3.0;
   const int K = L.K;
   if (K < 3) {
     const int code = point_code(L, (int)cx, (int)cy);
@@ -98,30 +112,28 @@ __device__ double footprint_cost(const sfw_launch &L, double x, double y, double
   }
   // Every footprint vertex is the end of one edge and the start of the next, so
   // its cell is computed once (the reference converts it twice, same result).
-  // Any vertex off the map makes the pose illegal (-3); which negative code wins
+  // Any vertex off the map makes the pose illegal (-3); which illegal code wins
   // when several apply does not matter to scoreTrajectory (all map to -1.0).
-  double fc = 0.0;
+  int fc = 0;
   double qx = L.footprint[0], qy = L.footprint[1];
   unsigned fx0, fy0;
-  if (!world_to_map(L, x + (qx * c - qy * s), y + (qx * s + qy * c), fx0, fy0)) return -3.0;
+  if (!world_to_map(L, inv_res, x + (qx * c - qy * s), y + (qx * s + qy * c), fx0, fy0)) return -3.0;
   unsigned x0 = fx0, y0 = fy0;
   for (int e = 0; e < K; ++e) {
     unsigned x1, y1;
     if (e + 1 < K) {
       qx = L.footprint[2 * (e + 1)];
       qy = L.footprint[2 * (e + 1) + 1];
-      if (!world_to_map(L, x + (qx * c - qy * s), y + (qx * s + qy * c), x1, y1)) return -3.0;
+      if (!world_to_map(L, inv_res, x + (qx * c - qy * s), y + (qx * s + qy * c), x1, y1)) return -3.0;
     } else {  // closing edge: back() -> front()
       x1 = fx0;
       y1 = fy0;
     }
-    const double lc = line_cost(L, (int)x0, (int)y0, (int)x1, (int)y1);
-    fc = fmax(lc, fc);
-    if (lc < 0) return lc;
+    fc = max(fc, line_max(L, (int)x0, (int)y0, (int)x1, (int)y1));
     x0 = x1;
     y0 = y1;
   }
-  return fc;
+  return static_cast<double>(fc);  // >= 254 (lethal / unknown on an edge): illegal, like the reference's -1 / -2
 }
 
 // reference sfw_planner.hpp:457-463
