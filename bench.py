@@ -235,13 +235,14 @@ def roofline_for(job, k2_ms, precision):
                          "(the K1->K2 robot-step table; algorithmic bytes are in roofline.hbm)") if tr else None,
         "flops_per_trajectory": flops_traj,
         "kernel_ms": k2_ms,
-        "launches_per_step": job.plan["chunks"] * (2 if job.plan["split_step"] > 0 else 1),
-        "shared_prefix": ({"split_step": job.plan["split_step"], "classes": job.plan["classes"],
-                           "samples": job.plan["samples"],
-                           "note": "steps [0, split_step) are simulated once per class of samples whose robot "
-                                   "trajectories coincide under the acceleration limits (bit-identical costs); "
-                                   "kernel_ms is the sum of the prefix and the suffix launch, `achieved` still "
-                                   "prices the full algorithmic work"} if job.plan["split_step"] > 0 else None),
+        "launches_per_step": job.plan["chunks"] * (1 + job.plan["levels"]),
+        "shared_prefix": ({"split_step": job.plan["split_step"], "levels": job.plan["levels"],
+                           "class_steps": job.plan["class_steps"],
+                           "sample_steps_replaced": job.plan["samples"] * job.plan["split_step"],
+                           "note": "steps [0, split_step) are simulated along a tree of classes of samples whose "
+                                   "robot trajectories coincide under the acceleration limits (bit-identical costs); "
+                                   "kernel_ms spans the prefix launches and the suffix launch, `achieved` still "
+                                   "prices the full algorithmic work"} if job.plan["levels"] > 0 else None),
         "note": "algorithmic flops per SURVEY.md §8d (48 per ordered pair incl. exp/atan2/sqrt as 1 op each); "
                 "non-MFMA vector peak for the dtype",
         "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,

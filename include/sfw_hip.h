@@ -216,19 +216,24 @@ int sfw_grid_sync(sfw_handle h);
 /* D2H of the cost vector (nullable) and the local selection (nullable). */
 int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out,
                    sfw_best_key *key_out);
-/* How the staged grid will be launched.  split_step > 0: the shared-prefix
+/* How the staged grid will be launched.  levels > 0: the shared-prefix
  * rollout is in use — under the acceleration limits (sfw_planner.hpp:457-463)
- * the robot's first split_step steps are bit-identical for all samples of a
- * class (same clipped linear x angular velocity sequences), so those steps are
- * simulated once per class (classes = sum over chunks of row classes x column
- * classes) and every sample resumes from its class's state.  Costs are
- * bit-identical to the plain rollout; SFW_PREFIX=0 in the environment of
- * sfw_create switches it off. */
+ * the robot's first steps are bit-identical for all samples of a class (same
+ * clipped linear x angular velocity sequences), and classes refine step by
+ * step, so the first split_step steps are simulated along a tree of `levels`
+ * levels of classes (class_steps class-steps in all instead of
+ * samples * split_step sample-steps) and every sample resumes from its class
+ * of the last level (`classes` of them).  Costs are bit-identical to the
+ * plain rollout; SFW_PREFIX=0 in the environment of sfw_create switches it
+ * off, SFW_PREFIX=3,7,12 forces the levels' end steps. */
 typedef struct sfw_plan_info {
-  int32_t split_step; /* 0: plain rollout                                   */
-  int32_t chunks;     /* launches of the K1->K2 table (SFW_TABLE_BUDGET_MB) */
-  int64_t classes;    /* items of the prefix phase                          */
-  int64_t samples;    /* nv * nw                                            */
+  int32_t split_step;  /* last shared step + 1; 0: plain rollout             */
+  int32_t levels;
+  int32_t chunks;      /* launches of the K1->K2 table (SFW_TABLE_BUDGET_MB) */
+  int32_t reserved;
+  int64_t classes;     /* classes of the last level, summed over chunks      */
+  int64_t class_steps; /* sum over levels of classes x steps of the level    */
+  int64_t samples;     /* nv * nw                                            */
 } sfw_plan_info;
 int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out);
 /* Per-kernel HIP events around the kernels of sfw_grid_launch, off by default

@@ -128,15 +128,25 @@ struct sfw_planner_s {
   bool staged = false, launched = false, launched_timed = false;
   bool timing = false;  // sfw_set_timing: record the per-kernel events sfw_last_launch_ms reads
 
-  // shared-prefix plan of the staged grid (sfw_device.h: sfw_cls_agent); P == 0: not used
-  struct chunk_classes { int32_t n_row_cls; size_t o_row_cls, o_row_rep; };  // offsets (ints) into d_cls
-  int prefix_P = 0, prefix_S = 0, prefix_ncol = 0;
+  // shared-prefix plan of the staged grid (sfw_device.h: sfw_cls_agent); no levels: not used
+  struct level_tables {               // offsets (ints) into d_cls
+    int32_t n_row = 0, n_col = 0;     // classes of the level: rows in this chunk x columns
+    size_t o_row_rep = 0, o_col_rep = 0;  // representative chunk-local row / column of a class
+    size_t o_row_src = 0, o_col_src = 0;  // class of the previous level a class resumes from (level > 0)
+  };
+  struct chunk_plan {
+    std::vector<level_tables> lv;
+    size_t o_row_cls = 0;             // chunk-local row -> row class of the last level
+  };
+  std::vector<int> prefix_steps;      // P(0) < P(1) < ...: level l integrates steps [P(l-1), P(l))
+  std::vector<chunk_plan> prefix_chunks;
+  size_t prefix_o_col_cls = 0;        // column -> column class of the last level
+  int prefix_S = 0;
   int64_t prefix_chunk = 0;
-  size_t prefix_o_col_cls = 0, prefix_o_col_rep = 0;
-  std::vector<chunk_classes> prefix_chunks;
-  dev_buf<int32_t> d_cls, cls_dead;
-  dev_buf<sfw_cls_agent> cls_state;
-  int prefix_env = -1;  // SFW_PREFIX: -1 automatic, 0 off, >0 forced split step
+  int64_t prefix_class_steps = 0, prefix_last_classes = 0;
+  dev_buf<int32_t> d_cls, cls_dead[2];
+  dev_buf<sfw_cls_agent> cls_state[2];  // ping-pong between levels
+  std::vector<int> prefix_env;          // SFW_PREFIX: empty automatic, {0} off, else forced split steps
 
   // per-sample outputs + per-chunk table
   dev_buf<int32_t> status, coll_step;
@@ -230,6 +240,10 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.rstep_stride = stride;
   L.points = nullptr;
   L.n_points = nullptr;
+  L.phase = SFW_PHASE_WHOLE;
+  L.step_begin = 0;
+  L.step_end = L.S;
+  L.resume = 0;
 }
 
 // ---- shared-prefix plan ---------------------------------------------------
@@ -273,13 +287,30 @@ void velocity_classes(const std::vector<double> &targets, double v0, double a_ma
   }
 }
 
-// Decide the split step P of the staged grid and lay the class tables out per chunk of whole rows.
+// Per-step cost of a launch of `items` work items, in units of one step of a SIMD-filling launch's wave
+// round: below one wave per issue slot of the GPU the FP64 dependency chains are exposed and a step takes
+// about 0.45 of a full round whatever the item count (cfg2: 10 us against 22 us), above it time is
+// proportional to the waves.
+double step_cost(double items, double items_per_wave) {
+  const double capacity = 1024.0 * 5.5;  // waves resident at once: 1024 SIMDs x 5-6 waves
+  const double x = items / items_per_wave / capacity;
+  return x <= 1.0 ? 0.45 + 0.55 * x : x;
+}
+
+// Decide the levels of the staged grid's shared-prefix tree and lay the class tables out per chunk of
+// whole rows.  A level ending at step p costs (p - q) steps over classes(p) items plus a launch and
+// the class records (0.4 of a round); the suffix costs (S - p) steps over all samples.  Dynamic
+// programme over the end step of the last level.
 int plan_prefix(sfw_handle h, int64_t chunk, int S) {
-  h->prefix_P = 0;
+  h->prefix_steps.clear();
   h->prefix_chunks.clear();
+  h->prefix_class_steps = h->prefix_last_classes = 0;
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
-  if (h->prefix_env == 0 || h->st_A < 2 || S < 2 || h->vy_samp != 0.0) return SFW_OK;
-  if (h->prefix_env < 0 && T < 4096) return SFW_OK;  // the GPU is not full: an extra launch costs more than it saves
+  const bool forced = !h->prefix_env.empty();
+  if ((forced && h->prefix_env[0] == 0) || h->st_A < 2 || S < 2 || h->vy_samp != 0.0) return SFW_OK;
+  if (!forced && T < 4096) return SFW_OK;  // the GPU is not full: extra launches cost more than they save
+  const int64_t rows_per_chunk = chunk / h->nw;
+  if (rows_per_chunk < 1) return SFW_OK;  // a single row does not fit the table budget: no sharing
   const double dt = h->params.sim_time / S;
   const int max_p = std::min(S - 1, 48);
   std::vector<std::vector<int32_t>> rc, cc;
@@ -291,66 +322,115 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
     return c[std::min<size_t>(static_cast<size_t>(p), c.size()) - 1];
   };
   auto count_at = [](const std::vector<int32_t> &n, int p) { return n[std::min<size_t>(static_cast<size_t>(p), n.size()) - 1]; };
-  int best_p = 0;
-  double best_saved = 0.0;
-  const int last_p = std::min<int>(max_p, static_cast<int>(std::max(nr.size(), nc.size())));
-  for (int p = 1; p <= last_p; ++p) {
-    const double saved = (static_cast<double>(T) - static_cast<double>(count_at(nr, p)) * count_at(nc, p)) * p;
-    if (saved > best_saved) { best_saved = saved; best_p = p; }
+  std::vector<int> steps;
+  if (forced) {
+    for (int p : h->prefix_env)
+      if (p >= 1 && p <= max_p) steps.push_back(p);
+  } else {
+    const double per_wave = static_cast<double>(sfw_samples_per_wave(h->st_A, std::min<int64_t>(T, rows_per_chunk * h->nw)));
+    const double launch_cost = 0.4, full = step_cost(static_cast<double>(T), per_wave);
+    const int last_p = std::min<int>(max_p, static_cast<int>(std::max(nr.size(), nc.size())));
+    std::vector<double> best(static_cast<size_t>(last_p) + 1, 0.0);
+    std::vector<int> from(static_cast<size_t>(last_p) + 1, 0);
+    double best_total = S * full;
+    int best_end = 0;
+    for (int p = 1; p <= last_p; ++p) {
+      const double c = step_cost(static_cast<double>(count_at(nr, p)) * count_at(nc, p), per_wave);
+      best[p] = 1e300;
+      for (int q = 0; q < p; ++q) {
+        const double v = best[q] + (p - q) * c + launch_cost;
+        if (v < best[p]) { best[p] = v; from[p] = q; }
+      }
+      const double total = best[p] + (S - p) * full;
+      if (total < best_total) { best_total = total; best_end = p; }
+    }
+    if (best_total > 0.97 * S * full) return SFW_OK;  // not worth the extra launches
+    for (int p = best_end; p > 0; p = from[p]) steps.push_back(p);
+    std::reverse(steps.begin(), steps.end());
   }
-  if (h->prefix_env > 0) best_p = std::min(h->prefix_env, max_p);
-  else if (best_saved < 0.05 * static_cast<double>(T) * S) return SFW_OK;
-  if (best_p < 1) return SFW_OK;
-  // chunks of whole rows
-  int64_t rows_per_chunk = chunk / h->nw;
-  if (rows_per_chunk < 1) return SFW_OK;  // a single row does not fit the table budget: no sharing
-  const std::vector<int32_t> &row_cls_g = level(rc, best_p), &col_cls = level(cc, best_p);
-  const int ncol = count_at(nc, best_p);
-  std::vector<int32_t> ints;  // col_cls | col_rep | per chunk: row_cls (local) | row_rep (local rows)
-  h->prefix_o_col_cls = ints.size();
-  ints.insert(ints.end(), col_cls.begin(), col_cls.end());
-  h->prefix_o_col_rep = ints.size();
-  {
-    std::vector<int32_t> rep(ncol, -1);
-    for (int i = 0; i < h->nw; ++i)
-      if (rep[col_cls[i]] < 0) rep[col_cls[i]] = i;
-    ints.insert(ints.end(), rep.begin(), rep.end());
+  if (steps.empty()) return SFW_OK;
+  const size_t n_lv = steps.size();
+
+  // ---- tables: columns (chunk-independent), then rows per chunk
+  std::vector<int32_t> ints;
+  auto append = [&](const std::vector<int32_t> &v) {
+    const size_t o = ints.size();
+    ints.insert(ints.end(), v.begin(), v.end());
+    return o;
+  };
+  // representatives (first member) of the classes of `cls` over the index range [i0, i1); ids are
+  // relabelled in order of first appearance; `local` receives the relabelled class of every index
+  auto relabel = [](const std::vector<int32_t> &cls, int64_t i0, int64_t i1, std::vector<int32_t> &local,
+                    std::vector<int32_t> &rep) {
+    std::map<int32_t, int32_t> ids;
+    local.clear();
+    rep.clear();
+    for (int64_t i = i0; i < i1; ++i) {
+      auto it = ids.find(cls[static_cast<size_t>(i)]);
+      if (it == ids.end()) {
+        it = ids.emplace(cls[static_cast<size_t>(i)], static_cast<int32_t>(rep.size())).first;
+        rep.push_back(static_cast<int32_t>(i - i0));
+      }
+      local.push_back(it->second);
+    }
+  };
+  struct axis_level { std::vector<int32_t> local, rep, src; };
+  // levels of one axis over [i0, i1): local classes, representatives, parent classes
+  auto axis_levels = [&](const std::vector<std::vector<int32_t>> &cls, int64_t i0, int64_t i1) {
+    std::vector<axis_level> out(n_lv);
+    for (size_t l = 0; l < n_lv; ++l) {
+      relabel(level(cls, steps[l]), i0, i1, out[l].local, out[l].rep);
+      if (l > 0)  // classes refine: the parent of a class is the previous level's class of its representative
+        for (int32_t r : out[l].rep) out[l].src.push_back(out[l - 1].local[static_cast<size_t>(r)]);
+    }
+    return out;
+  };
+  const std::vector<axis_level> cols = axis_levels(cc, 0, h->nw);
+  std::vector<size_t> o_col_rep(n_lv), o_col_src(n_lv);
+  for (size_t l = 0; l < n_lv; ++l) {
+    o_col_rep[l] = append(cols[l].rep);
+    o_col_src[l] = append(cols[l].src);
   }
+  h->prefix_o_col_cls = append(cols[n_lv - 1].local);
   int64_t max_cls = 0;
   for (int64_t r0 = 0; r0 < h->nv; r0 += rows_per_chunk) {
     const int64_t r1 = std::min<int64_t>(h->nv, r0 + rows_per_chunk);
-    std::map<int32_t, int32_t> local;
-    std::vector<int32_t> lc, rep;
-    for (int64_t r = r0; r < r1; ++r) {
-      auto it = local.find(row_cls_g[r]);
-      if (it == local.end()) {
-        it = local.emplace(row_cls_g[r], static_cast<int32_t>(rep.size())).first;
-        rep.push_back(static_cast<int32_t>(r - r0));
-      }
-      lc.push_back(it->second);
+    const std::vector<axis_level> rows = axis_levels(rc, r0, r1);
+    sfw_planner_s::chunk_plan cp;
+    for (size_t l = 0; l < n_lv; ++l) {
+      sfw_planner_s::level_tables t;
+      t.n_row = static_cast<int32_t>(rows[l].rep.size());
+      t.n_col = static_cast<int32_t>(cols[l].rep.size());
+      t.o_row_rep = append(rows[l].rep);
+      t.o_row_src = append(rows[l].src);
+      t.o_col_rep = o_col_rep[l];
+      t.o_col_src = o_col_src[l];
+      cp.lv.push_back(t);
+      const int64_t n = static_cast<int64_t>(t.n_row) * t.n_col;
+      max_cls = std::max(max_cls, n);
+      h->prefix_class_steps += n * (steps[l] - (l ? steps[l - 1] : 0));
+      if (l + 1 == n_lv) h->prefix_last_classes += n;
     }
-    sfw_planner_s::chunk_classes c;
-    c.n_row_cls = static_cast<int32_t>(rep.size());
-    c.o_row_cls = ints.size();
-    ints.insert(ints.end(), lc.begin(), lc.end());
-    c.o_row_rep = ints.size();
-    ints.insert(ints.end(), rep.begin(), rep.end());
-    h->prefix_chunks.push_back(c);
-    max_cls = std::max<int64_t>(max_cls, static_cast<int64_t>(c.n_row_cls) * ncol);
+    cp.o_row_cls = append(rows[n_lv - 1].local);
+    h->prefix_chunks.push_back(cp);
   }
   SFW_HIP(h, h->d_cls.reserve(ints.size()));
   SFW_HIP(h, h->pin_cls.reserve(sizeof(int32_t) * ints.size()));
   std::memcpy(h->pin_cls.p, ints.data(), sizeof(int32_t) * ints.size());
   SFW_HIP(h, hipMemcpyAsync(h->d_cls.p, h->pin_cls.p, sizeof(int32_t) * ints.size(), hipMemcpyHostToDevice, h->stream));
   SFW_HIP(h, h->pin_cls.mark(h->stream));
-  SFW_HIP(h, h->cls_dead.reserve(static_cast<size_t>(max_cls)));
-  SFW_HIP(h, h->cls_state.reserve(static_cast<size_t>(max_cls) * h->st_A));
-  if (std::getenv("SFW_DEBUG_PLAN"))
-    std::fprintf(stderr, "[sfw] shared prefix: P=%d of S=%d, %d x %d classes of %d x %d samples, %zu chunk(s)\n", best_p, S,
-                 count_at(nr, best_p), ncol, h->nv, h->nw, h->prefix_chunks.size());
-  h->prefix_P = best_p;
+  for (size_t b = 0; b < (n_lv > 1 ? 2u : 1u); ++b) {
+    SFW_HIP(h, h->cls_dead[b].reserve(static_cast<size_t>(max_cls)));
+    SFW_HIP(h, h->cls_state[b].reserve(static_cast<size_t>(max_cls) * h->st_A));
+  }
+  if (std::getenv("SFW_DEBUG_PLAN")) {
+    std::fprintf(stderr, "[sfw] shared prefix, %d x %d samples, S=%d, %zu chunk(s):", h->nv, h->nw, S, h->prefix_chunks.size());
+    for (size_t l = 0; l < n_lv; ++l)
+      std::fprintf(stderr, " [%d,%d) %d x %d;", l ? steps[l - 1] : 0, steps[l], count_at(nr, steps[l]), count_at(nc, steps[l]));
+    std::fprintf(stderr, " [%d,%d) samples\n", steps.back(), S);
+  }
+  h->prefix_steps = steps;
   h->prefix_S = S;
-  h->prefix_ncol = ncol;
   h->prefix_chunk = rows_per_chunk * h->nw;
   return SFW_OK;
 }
@@ -443,7 +523,7 @@ int launch_common(sfw_handle h) {
   if (h->st_A > 0 && lds > 160 * 1024)
     return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
   // the shared-prefix plan was laid out for the staged step count and for chunks of whole rows
-  const bool prefix = h->prefix_P > 0 && h->prefix_S == S && h->prefix_P < S && h->prefix_chunk <= chunk;
+  const bool prefix = !h->prefix_steps.empty() && h->prefix_S == S && h->prefix_chunk <= chunk;
   if (prefix) chunk = h->prefix_chunk;
   const bool timing = h->timing;
   if (timing) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
@@ -471,20 +551,40 @@ int launch_common(sfw_handle h) {
       SFW_HIP(h, sfw_launch_rollout_costmap(L, h->side));
       SFW_HIP(h, hipEventRecord(h->ev_side, h->side));
       if (timing) SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
-      const sfw_planner_s::chunk_classes &cc = h->prefix_chunks[static_cast<size_t>(c)];
-      L.step_split = h->prefix_P;
-      L.n_col_cls = h->prefix_ncol;
-      L.n_cls = cc.n_row_cls * h->prefix_ncol;
-      L.row_cls = h->d_cls.p + cc.o_row_cls;
-      L.row_rep = h->d_cls.p + cc.o_row_rep;
-      L.col_cls = h->d_cls.p + h->prefix_o_col_cls;
-      L.col_rep = h->d_cls.p + h->prefix_o_col_rep;
-      L.cls_state = h->cls_state.p;
-      L.cls_dead = h->cls_dead.p;
-      L.phase = SFW_PHASE_PREFIX;
-      SFW_HIP(h, sfw_launch_social(L, h->stream));
+      const sfw_planner_s::chunk_plan &cp = h->prefix_chunks[static_cast<size_t>(c)];
+      const int32_t *tab = h->d_cls.p;
+      const size_t n_lv = h->prefix_steps.size();
+      for (size_t l = 0; l < n_lv; ++l) {  // the tree of shared steps, coarsest classes first
+        const sfw_planner_s::level_tables &t = cp.lv[l];
+        L.phase = SFW_PHASE_PREFIX;
+        L.step_begin = l ? h->prefix_steps[l - 1] : 0;
+        L.step_end = h->prefix_steps[l];
+        L.n_cls = t.n_row * t.n_col;
+        L.n_col_cls = t.n_col;
+        L.row_rep = tab + t.o_row_rep;
+        L.col_rep = tab + t.o_col_rep;
+        L.resume = l > 0;
+        if (l > 0) {
+          L.n_col_src = cp.lv[l - 1].n_col;
+          L.row_src = tab + t.o_row_src;
+          L.col_src = tab + t.o_col_src;
+          L.in_state = h->cls_state[(l - 1) & 1].p;
+          L.in_dead = h->cls_dead[(l - 1) & 1].p;
+        }
+        L.out_state = h->cls_state[l & 1].p;
+        L.out_dead = h->cls_dead[l & 1].p;
+        SFW_HIP(h, sfw_launch_social(L, h->stream));
+      }
       SFW_HIP(h, hipStreamWaitEvent(h->stream, h->ev_side, 0));
       L.phase = SFW_PHASE_SUFFIX;
+      L.step_begin = h->prefix_steps.back();
+      L.step_end = S;
+      L.resume = 1;
+      L.n_col_src = cp.lv[n_lv - 1].n_col;
+      L.row_src = tab + cp.o_row_cls;
+      L.col_src = tab + h->prefix_o_col_cls;
+      L.in_state = h->cls_state[(n_lv - 1) & 1].p;
+      L.in_dead = h->cls_dead[(n_lv - 1) & 1].p;
       SFW_HIP(h, sfw_launch_social(L, h->stream));
     } else {
       SFW_HIP(h, sfw_launch_rollout(L, h->stream));
@@ -574,7 +674,17 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
   if (!h) return SFW_ERR_HIP;
   h->params = *params;
   h->device = device;
-  if (const char *b = std::getenv("SFW_PREFIX")) h->prefix_env = std::atoi(b);
+  if (const char *b = std::getenv("SFW_PREFIX")) {  // "0" off, "10" one split, "3,7,12" several levels
+    for (const char *q = b; *q;) {
+      char *end = nullptr;
+      const long v = std::strtol(q, &end, 10);
+      if (end == q) break;
+      if (v >= 0) h->prefix_env.push_back(static_cast<int>(v));
+      q = (*end == ',') ? end + 1 : end;
+    }
+    std::sort(h->prefix_env.begin(), h->prefix_env.end());
+    h->prefix_env.erase(std::unique(h->prefix_env.begin(), h->prefix_env.end()), h->prefix_env.end());
+  }
   if (const char *b = std::getenv("SFW_TABLE_BUDGET_MB")) {
     long mb = std::atol(b);
     if (mb > 0) h->table_budget_bytes = static_cast<size_t>(mb) << 20;
@@ -616,8 +726,8 @@ int sfw_destroy(sfw_handle h) {
   h->pin_out.release();
   h->pin_cls.release();
   h->d_cls.release();
-  h->cls_dead.release();
-  h->cls_state.release();
+  for (auto &b : h->cls_dead) b.release();
+  for (auto &b : h->cls_state) b.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto &e : h->chunk_ev)
@@ -807,12 +917,14 @@ int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out) {
   if (!h || !out) return SFW_ERR_INVALID_ARG;
   if (!h->staged) return fail(h, SFW_ERR_STATE, "grid_plan_info before grid_stage");
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
-  out->split_step = h->prefix_P;
+  out->split_step = h->prefix_steps.empty() ? 0 : h->prefix_steps.back();
+  out->levels = static_cast<int32_t>(h->prefix_steps.size());
+  out->reserved = 0;
   out->samples = T;
-  out->classes = 0;
-  if (h->prefix_P > 0) {
+  out->classes = h->prefix_last_classes;
+  out->class_steps = h->prefix_class_steps;
+  if (!h->prefix_steps.empty()) {
     out->chunks = static_cast<int32_t>(h->prefix_chunks.size());
-    for (const auto &c : h->prefix_chunks) out->classes += static_cast<int64_t>(c.n_row_cls) * h->prefix_ncol;
   } else {
     const int S = num_steps_of(h->params);
     int64_t chunk = static_cast<int64_t>(std::min(h->rstep.cap, std::min(h->frame.cap, h->fcode.cap)) / S);

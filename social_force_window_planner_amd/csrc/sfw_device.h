@@ -46,14 +46,16 @@ struct sfw_derived {
 
 // Shared-prefix rollout (K2).  Under the acceleration limits the robot's first P steps are
 // bit-identical for every sample of a CLASS (same clipped linear-velocity sequence x same clipped
-// angular-velocity sequence), hence so is the whole pedestrian simulation of those steps.  Phase 1
-// runs steps [0,P) once per class and leaves this record per (class, agent); phase 2 resumes every
-// sample from its class's record for steps [P,S).  Same arithmetic on the same values in the same
-// order: costs are bit-identical to the unshared rollout.
+// angular-velocity sequence), hence so is the whole pedestrian simulation of those steps.  Classes
+// refine as P grows, so the shared steps form a tree: level l simulates steps [P(l-1), P(l)) once per
+// class of level l, each class resuming from the record its parent class (level l-1) left and leaving
+// its own 64-byte record per agent; the suffix phase resumes every sample from its class of the last
+// level for steps [P(last), S).  Same arithmetic on the same values in the same order: costs are
+// bit-identical to the unshared rollout.
 struct sfw_cls_agent {
-  double px, py, vx, vy;  // state after step P-1
-  double fx, fy;          // desired + obstacle (+ group) force at that state = step P's starting force
-  double sw;              // the agent slot's social-work sum over steps [0,P)
+  double px, py, vx, vy;  // state after the level's last step
+  double fx, fy;          // desired + obstacle (+ group) force at that state = the next step's starting force
+  double sw;              // the agent slot's social-work sum over the steps so far
   int32_t hasgoal, pad;
 };
 enum { SFW_PHASE_WHOLE = 0, SFW_PHASE_PREFIX = 1, SFW_PHASE_SUFFIX = 2 };
@@ -95,16 +97,23 @@ struct sfw_launch {
   const int32_t *grp_mem;          // grp_off[NG] member agent indices, ascending per group
   int32_t NG;
   int32_t n_grp_mem;
-  // shared-prefix rollout (see sfw_cls_agent); chunks are whole grid rows when phase != WHOLE
+  // shared-prefix rollout (see sfw_cls_agent); chunks are whole grid rows when phase != WHOLE.
+  // Items of a PREFIX launch are the classes of one level (row class x column class), items of a
+  // SUFFIX / WHOLE launch are the chunk's samples.
   int32_t phase;                 // SFW_PHASE_*
-  int32_t step_split;            // P
-  int32_t n_cls, n_col_cls;      // classes in this chunk = row classes x column classes
-  const int32_t *row_cls;        // [chunk rows]   row (linvel) class of a chunk-local row
-  const int32_t *row_rep;        // [row classes]  chunk-local row representing a row class
-  const int32_t *col_cls;        // [nw]           column (angvel) class
-  const int32_t *col_rep;        // [n_col_cls]    column representing a column class
-  sfw_cls_agent *cls_state;      // [n_cls][A]
-  int32_t *cls_dead;             // [n_cls] 0, or 2 + step of a pedestrian contact inside the prefix
+  int32_t step_begin, step_end;  // steps this launch integrates
+  int32_t resume;                // 1: start from in_state records instead of the initial agents
+  int32_t n_cls, n_col_cls;      // PREFIX: classes of this level, its column classes
+  const int32_t *row_rep;        // PREFIX [row classes]  chunk-local row whose robot records represent the class
+  const int32_t *col_rep;        // PREFIX [n_col_cls]    column likewise
+  // where an item resumes from: record row_src[r] * n_col_src + col_src[c] of in_state, with (r, c) =
+  // (row class, column class) of a PREFIX item, (chunk-local row, column) of a sample
+  int32_t n_col_src;
+  const int32_t *row_src, *col_src;
+  const sfw_cls_agent *in_state;  // [source classes][A]
+  const int32_t *in_dead;         // [source classes] 0, or 2 + step of a pedestrian contact so far
+  sfw_cls_agent *out_state;       // PREFIX [n_cls][A]
+  int32_t *out_dead;              // PREFIX [n_cls]
   // flat social kernel: pair u -> packed LDS byte offsets (16*i | 16*j << 16), see sfw_launch_pair_table
   const uint32_t *pair_tab;
   // per-sample outputs, indexed by GLOBAL sample index

@@ -723,20 +723,29 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_l
 
 // Stage the per-launch constants and the initial agent state into LDS; returns
 // false when every sample of this wave was already rejected by K1.
-// Work items of a K2 launch: samples of the chunk (whole rollout, suffix phase) or classes of the
-// chunk (prefix phase, see sfw_cls_agent).
+// Work items of a K2 launch: samples of the chunk (whole rollout, suffix phase) or classes of one
+// level (prefix phases, see sfw_cls_agent).
 __device__ __forceinline__ int64_t item_count(const sfw_launch &L) {
   return L.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L.n_cls) : L.chunk_count;
 }
-__device__ __forceinline__ int64_t class_of_sample(const sfw_launch &L, int64_t local) {
-  const int64_t row = local / L.nw, col = local - row * L.nw;  // chunks are whole rows when classes exist
-  return static_cast<int64_t>(L.row_cls[row]) * L.n_col_cls + L.col_cls[col];
+// (row, column) coordinates of an item: class coordinates for a PREFIX item, grid coordinates of a sample
+__device__ __forceinline__ void item_coords(const sfw_launch &L, int64_t item, int64_t &r, int64_t &c) {
+  const int64_t width = L.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L.n_col_cls) : static_cast<int64_t>(L.nw);
+  r = item / width;  // chunks are whole rows when classes exist
+  c = item - r * width;
+}
+// record of in_state an item resumes from
+__device__ __forceinline__ int64_t source_class_of_item(const sfw_launch &L, int64_t item) {
+  int64_t r, c;
+  item_coords(L, item, r, c);
+  return static_cast<int64_t>(L.row_src[r]) * L.n_col_src + L.col_src[c];
 }
 // chunk-local sample whose K1 robot-step records an item reads
 __device__ __forceinline__ int64_t robot_sample_of_item(const sfw_launch &L, int64_t item) {
   if (L.phase != SFW_PHASE_PREFIX) return item;
-  const int64_t rc = item / L.n_col_cls, cc = item - rc * L.n_col_cls;
-  return static_cast<int64_t>(L.row_rep[rc]) * L.nw + L.col_rep[cc];
+  int64_t r, c;
+  item_coords(L, item, r, c);
+  return static_cast<int64_t>(L.row_rep[r]) * L.nw + L.col_rep[c];
 }
 
 // Stage the per-launch constants and the initial dead flags into LDS; returns false when no item of
@@ -765,10 +774,11 @@ __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout
     int dead = 1;
     if (lane < Gn) {
       if (L.phase == SFW_PHASE_PREFIX) {
-        dead = 0;  // a class is simulated whatever K1 said about its members
+        // a class is simulated whatever K1 said about its members, unless its parent already ended in a contact
+        dead = L.resume ? L.in_dead[source_class_of_item(L, first_local + lane)] : 0;
       } else {
         dead = (L.status[L.chunk_begin + first_local + lane] != SFW_ST_VALID);
-        if (L.phase == SFW_PHASE_SUFFIX && dead == 0) dead = L.cls_dead[class_of_sample(L, first_local + lane)];
+        if (L.resume && dead == 0) dead = L.in_dead[source_class_of_item(L, first_local + lane)];
       }
     }
     s.dead[lane] = dead;
@@ -845,13 +855,13 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   const int64_t first_local = static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x)) * G;
   const int64_t remain = item_count(L) - first_local;
   const int Gn = remain < G ? static_cast<int>(remain) : G;
-  const int step_begin = L.phase == SFW_PHASE_SUFFIX ? L.step_split : 0;
-  const int step_end = L.phase == SFW_PHASE_PREFIX ? L.step_split : L.S;
+  const int step_begin = L.step_begin, step_end = L.step_end;
   const sfm_consts<R> k = make_consts<R, false>(L);
   const double inv_O = L.k.inv_O;
   if (!stage_wave<GROUPS, true>(L, s, lane, G, Gn, first_local)) {
-    // nothing to integrate; samples that inherit a contact from their class still get their verdict
+    // nothing to integrate; items that inherit a contact still pass the verdict on
     if (L.phase == SFW_PHASE_SUFFIX) finish_wave(L, s, lane, G, Gn, GA, first_local, 0.0);
+    if (L.phase == SFW_PHASE_PREFIX && lane < Gn) L.out_dead[first_local + lane] = s.dead[lane];
     return;
   }
 
@@ -874,9 +884,9 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     sl_[r] = slc;
     const int i = i_[r];
     fx[r] = fy[r] = sw[r] = 0.0;
-    if (L.phase == SFW_PHASE_SUFFIX) {  // resume from the class record
+    if (L.resume) {  // resume from the record of the item's (parent) class
       if (ok_[r] && g_[r] < Gn) {
-        const sfw_cls_agent c = L.cls_state[class_of_sample(L, first_local + g_[r]) * A + i];
+        const sfw_cls_agent c = L.in_state[source_class_of_item(L, first_local + g_[r]) * A + i];
         s.pos[sl] = double2{c.px, c.py};
         s.vel[sl] = double2{c.vx, c.vy};
         s.frj[sl] = double2{0.0, 0.0};
@@ -936,7 +946,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
       }
   };
   if constexpr (GROUPS) {
-    if (L.phase != SFW_PHASE_SUFFIX) add_group_forces();  // the class record's force already has them
+    if (!L.resume) add_group_forces();  // a class record's force already has them
   }
 
   const int rows = A / 2;            // half ring; for even A the last row is half length
@@ -1026,9 +1036,9 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         c.fx = fx[r]; c.fy = fy[r]; c.sw = sw[r];
         c.hasgoal = s.hasgoal[sl_[r]];
         c.pad = 0;
-        L.cls_state[(first_local + g_[r]) * A + i_[r]] = c;
+        L.out_state[(first_local + g_[r]) * A + i_[r]] = c;
       }
-    if (lane < Gn) L.cls_dead[first_local + lane] = s.dead[lane];
+    if (lane < Gn) L.out_dead[first_local + lane] = s.dead[lane];
     return;
   }
   double sw_acc = 0.0;
@@ -1079,7 +1089,7 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   (void)G_unused;
   const int lane = threadIdx.x;
-  const int A = L.A, O = L.O, S = L.S;
+  const int A = L.A, O = L.O;
   const int NG = GROUPS ? L.NG : 0;
   const int cap = CAP > 0 ? CAP : A;
   const int VEL = 16 * cap, FRJ = 32 * cap, FRC = 48 * cap;  // byte offsets from pos[] (immediates when CAP > 0)
@@ -1087,16 +1097,16 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
   const int64_t first_local = xcd_contiguous(blockIdx.x, gridDim.x);
   const sfm_consts<R> k = make_consts<R, true>(L);
   const double inv_O = L.k.inv_O;
-  const int step_begin = L.phase == SFW_PHASE_SUFFIX ? L.step_split : 0;
-  const int step_end = L.phase == SFW_PHASE_PREFIX ? L.step_split : S;
+  const int step_begin = L.step_begin, step_end = L.step_end;
   if (!stage_wave<GROUPS, GROUPS>(L, s, lane, 1, 1, first_local)) {
     if (L.phase == SFW_PHASE_SUFFIX) finish_wave(L, s, lane, 1, 1, A, first_local, 0.0);  // inherited contact
+    if (L.phase == SFW_PHASE_PREFIX && lane == 0) L.out_dead[first_local] = s.dead[0];
     return;
   }
   const int64_t rsample = robot_sample_of_item(L, first_local);
 
-  if (L.phase == SFW_PHASE_SUFFIX) {  // resume from the class record
-    const sfw_cls_agent *rec = L.cls_state + class_of_sample(L, first_local) * A;
+  if (L.resume) {  // resume from the record of the item's (parent) class
+    const sfw_cls_agent *rec = L.in_state + source_class_of_item(L, first_local) * A;
     for (int sl = lane; sl < A; sl += WAVE) {
       const sfw_cls_agent c = rec[sl];
       s.pos[sl] = double2{c.px, c.py};
@@ -1153,7 +1163,7 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
     __syncthreads();
   };
   if constexpr (GROUPS) {
-    if (L.phase != SFW_PHASE_SUFFIX) add_group_forces();  // the class record's force already has them
+    if (!L.resume) add_group_forces();  // a class record's force already has them
   }
 
   const int P = A * (A - 1) / 2;  // unordered pairs
@@ -1200,7 +1210,7 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
     if constexpr (GROUPS) add_group_forces();
   }
   if (L.phase == SFW_PHASE_PREFIX) {  // leave the class record
-    sfw_cls_agent *rec = L.cls_state + first_local * A;
+    sfw_cls_agent *rec = L.out_state + first_local * A;
     for (int sl = lane; sl < A; sl += WAVE) {
       const double2 p = s.pos[sl], v = s.vel[sl], f = s.frc[sl];
       sfw_cls_agent c;
@@ -1210,7 +1220,7 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
       c.pad = 0;
       rec[sl] = c;
     }
-    if (lane == 0) L.cls_dead[first_local] = s.dead[0];
+    if (lane == 0) L.out_dead[first_local] = s.dead[0];
     return;
   }
   double sw_acc = 0.0;

@@ -53,7 +53,7 @@ def test_bit_identical_for_every_split(hip_mod, name, nv, nw, people):
     p = _params(w)
     ref, bref = _score(hip_mod, scene, p, 0)
     assert (ref >= 0).sum() > 0
-    for prefix in (-1, 1, 7, w.n_steps - 1):
+    for prefix in (-1, 1, 7, w.n_steps - 1, "2,5,9", "1,2,3,4,5,6,7,8", "3,30"):
         c, b = _score(hip_mod, scene, p, prefix)
         assert _same(ref, c), f"SFW_PREFIX={prefix}: costs differ"
         assert b == bref
@@ -81,7 +81,7 @@ def test_contacts_inside_the_prefix_and_points(hip_mod):
     p = _params(w)
     ref, bref, nref = _score(hip_mod, scene, p, 0, want_points=True)
     assert (ref == -1.0).sum() > 0
-    for prefix in (3, 20):
+    for prefix in (3, 20, "1,2,4,8,16", -1):
         c, b, n = _score(hip_mod, scene, p, prefix, want_points=True)
         assert _same(ref, c) and b == bref and np.array_equal(n, nref)
 
@@ -98,7 +98,7 @@ def test_zero_sample_as_class_representative(hip_mod):
     ga = (0.2, 0.0, 0.3, 2.0, 0.5)  # 5 mm/s and 7.5 mrad/s per step
     ref, bref = _score(hip_mod, scene, p, 0, goal_args=ga)
     assert ref[0] == -2.0
-    for prefix in (1, 5, 30):
+    for prefix in (1, 5, 30, "2,9,17"):
         c, b = _score(hip_mod, scene, p, prefix, goal_args=ga)
         assert _same(ref, c) and b == bref
 
@@ -112,7 +112,7 @@ def test_chunked_launch_groups_obstacles_and_f32(hip_mod):
     for prec in ({}, {"precision": SFW_PRECISION_F32}):
         p = _params(w, **prec)
         ref, bref = _score(hip_mod, scene, p, 0)
-        for prefix, budget in ((6, None), (6, 1), (-1, 1)):
+        for prefix, budget in ((6, None), (6, 1), (-1, 1), ("2,4,9", 1)):
             c, b = _score(hip_mod, scene, p, prefix, budget_mb=budget)
             assert _same(ref, c), (prec, prefix, budget)
             assert b == bref
@@ -127,18 +127,20 @@ def test_plan_info_reports_the_split(hip_mod):
     g.load_scene(scene)
     g.stage(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
     info = g.plan_info()
-    assert info["samples"] == 4096 and info["chunks"] == 1
+    assert info["samples"] == 4096 and info["chunks"] == 1 and info["levels"] >= 1
     assert 1 <= info["split_step"] < w.n_steps and 0 < info["classes"] < info["samples"]
+    assert 0 < info["class_steps"] < info["samples"] * info["split_step"]
     small = syn.make_scene("ref5x9")
     g.load_scene(small)
     g.stage(small.robot_state, small.linvels, small.angvels, small.goal_args)
-    assert g.plan_info() == {"split_step": 0, "chunks": 1, "classes": 0, "samples": 45}
+    assert g.plan_info() == {"split_step": 0, "levels": 0, "chunks": 1, "classes": 0, "class_steps": 0, "samples": 45}
     # targets far outside the window reachable in the horizon: every sample shares every step but the last
     lin = np.linspace(5.0, 6.0, 64)
     ang = np.linspace(3.0, 4.0, 64)
     g.load_scene(scene)
     g.stage(scene.robot_state, lin, ang, scene.goal_args)
     info = g.plan_info()
-    assert info["split_step"] == w.n_steps - 1 and info["classes"] == 1
+    assert info["split_step"] == w.n_steps - 1 and info["classes"] == 1 and info["levels"] == 1
+    assert info["class_steps"] == w.n_steps - 1
     c, b = g.score_grid(scene.robot_state, lin, ang, scene.goal_args)
     assert np.all(c == c[0]) or (c < 0).any()  # one trajectory, 4096 times (or all rejected alike)
