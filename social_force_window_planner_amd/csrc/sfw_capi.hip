@@ -299,7 +299,7 @@ double step_cost(double items, double items_per_wave) {
 
 // Decide the levels of the staged grid's shared-prefix tree and lay the class tables out per chunk of
 // whole rows.  A level ending at step p costs (p - q) steps over classes(p) items plus a launch and
-// the class records (0.4 of a round); the suffix costs (S - p) steps over all samples.  Dynamic
+// the class records (0.4 to 1.0 of a round); the suffix costs (S - p) steps over all samples.  Dynamic
 // programme over the end step of the last level.
 int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   h->prefix_steps.clear();
@@ -328,7 +328,7 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
       if (p >= 1 && p <= max_p) steps.push_back(p);
   } else {
     const double per_wave = static_cast<double>(sfw_samples_per_wave(h->st_A, std::min<int64_t>(T, rows_per_chunk * h->nw)));
-    const double launch_cost = 0.4, full = step_cost(static_cast<double>(T), per_wave);
+    const double full = step_cost(static_cast<double>(T), per_wave);
     const int last_p = std::min<int>(max_p, static_cast<int>(std::max(nr.size(), nc.size())));
     std::vector<double> best(static_cast<size_t>(last_p) + 1, 0.0);
     std::vector<int> from(static_cast<size_t>(last_p) + 1, 0);
@@ -336,6 +336,9 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
     int best_end = 0;
     for (int p = 1; p <= last_p; ++p) {
       const double c = step_cost(static_cast<double>(count_at(nr, p)) * count_at(nc, p), per_wave);
+      // per extra launch: dispatch + class records for an under-filled level; a level that fills the GPU
+      // also pays its ramp-up and tail (measured: 0.4 / 1.0 pick the fastest plans at cfg2 / target)
+      const double launch_cost = c < 1.0 ? 0.4 : 1.0;
       best[p] = 1e300;
       for (int q = 0; q < p; ++q) {
         const double v = best[q] + (p - q) * c + launch_cost;

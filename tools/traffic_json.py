@@ -1,6 +1,8 @@
 """Build profiles/r01_traffic.json from the FETCH_SIZE/WRITE_SIZE summaries written by tools/profile.sh.
-usage: traffic_json.py <workload>=<traffic.txt>[:<K2 launches per step>] ... > profiles/r01_traffic.json
-(the summaries hold means per dispatch; with the shared-prefix rollout K2 is two dispatches per step)"""
+usage: traffic_json.py <workload>=<traffic.txt> ... > profiles/r01_traffic.json
+The summaries hold means per dispatch; a bench step dispatches K2 several times (shared-prefix levels +
+suffix, possibly in both kernel organisations), so bytes are converted to per-step sums using the
+dispatch counts (one sfw_rollout_kernel dispatch per step)."""
 import json
 import re
 import sys
@@ -8,30 +10,30 @@ import sys
 out = {}
 for arg in sys.argv[1:]:
     name, path = arg.split("=")
-    per_step = 1
-    if ":" in path:
-        path, n = path.rsplit(":", 1)
-        per_step = int(n)
     kernels, cur = {}, None
     for line in open(path):
-        m = re.match(r"== (\S.*?)\s+dispatches=", line)
+        m = re.match(r"== (\S.*?)\s+dispatches=(\d+)", line)
         if m:
-            cur = kernels.setdefault(m.group(1), {})
+            cur = kernels.setdefault(m.group(1), {"dispatches": int(m.group(2))})
             continue
         m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+([\d.]+)", line)
         if m and cur is not None:
             cur["fetch_bytes" if m.group(1) == "FETCH_SIZE" else "write_bytes"] = float(m.group(2)) * 1024.0
     kernels = {k: v for k, v in kernels.items() if "pair_table" not in k}
-    k2 = next(k for k in kernels if "social" in k)
+    steps = kernels["sfw_rollout_kernel"]["dispatches"]
+    per_step = {}
+    for k, v in kernels.items():
+        n = v["dispatches"] / steps
+        per_step[k] = {"dispatches_per_step": n, "fetch_bytes": v.get("fetch_bytes", 0.0) * n,
+                       "write_bytes": v.get("write_bytes", 0.0) * n}
+    k2 = [k for k in per_step if "social" in k]
     out[name] = {
-        "kernels": kernels,
+        "kernels": per_step,
         "k2": k2,
-        "k2_launches_per_step": per_step,
-        "k2_bytes": per_step * (kernels[k2]["fetch_bytes"] + kernels[k2]["write_bytes"]),
-        "all_kernels_bytes": sum((per_step if k == k2 else 1) * (v.get("fetch_bytes", 0) + v.get("write_bytes", 0))
-                                 for k, v in kernels.items()),
+        "k2_bytes": sum(per_step[k]["fetch_bytes"] + per_step[k]["write_bytes"] for k in k2),
+        "all_kernels_bytes": sum(v["fetch_bytes"] + v["write_bytes"] for v in per_step.values()),
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile.sh), KB x 1024, "
-                  "mean per dispatch; 32-byte-per-lane records, so the gfx950 half-reporting of 16 B/lane streams "
-                  "does not apply (K2 fetch == K1->K2 robot-step table size)",
+                  "mean per dispatch x dispatches per bench step; 32-byte-per-lane records, so the gfx950 "
+                  "half-reporting of 16 B/lane streams does not apply",
     }
 json.dump(out, sys.stdout, indent=1)
