@@ -144,3 +144,23 @@ def test_plan_info_reports_the_split(hip_mod):
     assert info["class_steps"] == w.n_steps - 1
     c, b = g.score_grid(scene.robot_state, lin, ang, scene.goal_args)
     assert np.all(c == c[0]) or (c < 0).any()  # one trajectory, 4096 times (or all rejected alike)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scenes_random_levels(hip_mod, seed):
+    """The random scenes of test_random_scenes_gpu (agent counts 0..150, footprints, laser points, step
+    counts, non-default parameters) under random level sets: bitwise the plain rollout."""
+    import test_random_scenes_gpu as gen
+
+    scene, p, rs, ga, lin, ang = gen._case(500 + seed)
+    rng = np.random.default_rng(seed)
+    S = scene.workload.n_steps
+    if S < 2 or len(scene.agents) < 2:
+        pytest.skip("nothing to share")
+    n_lv = int(rng.integers(1, 6))
+    levels = sorted(set(int(v) for v in rng.integers(1, S, size=n_lv)))
+    scene = dataclasses.replace(scene, robot_state=rs, linvels=lin, angvels=ang)
+    ref, bref = _score(hip_mod, scene, p, 0, goal_args=ga)
+    c, b = _score(hip_mod, scene, p, ",".join(map(str, levels)), goal_args=ga)
+    assert _same(ref, c), f"levels {levels}"
+    assert b == bref
