@@ -236,6 +236,19 @@ typedef struct sfw_plan_info {
   int64_t samples;     /* nv * nw                                            */
 } sfw_plan_info;
 int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out);
+/* The plan a single-chunk stage of this grid would choose, computed on the
+ * host alone (no handle, no device): end steps of the levels and their class
+ * counts (row classes x column classes), up to cap entries; *n_levels = 0
+ * when sharing does not pay (fewer than 4096 samples, fewer than two agents,
+ * or nothing to share).  vx0 / vtheta0: the robot's current velocities,
+ * acc_*: sfw_goal_args, num_steps as scoreTrajectory derives it (:519-525). */
+int sfw_plan_shared_prefix(const double *linvels, int32_t nv,
+                           const double *angvels, int32_t nw, double vx0,
+                           double vtheta0, double acc_x, double acc_theta,
+                           double sim_time, int32_t num_steps,
+                           int32_t n_agents, int32_t *level_ends,
+                           int64_t *level_classes, int32_t cap,
+                           int32_t *n_levels);
 /* Per-kernel HIP events around the kernels of sfw_grid_launch, off by default
  * (a control cycle is latency-bound; four event records cost as much as a
  * kernel).  Measurement tooling (bench.py) switches them on. */

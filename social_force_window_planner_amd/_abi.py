@@ -157,6 +157,7 @@ EXPORTED_SYMBOLS = (
     "sfw_grid_sync",
     "sfw_grid_fetch",
     "sfw_grid_plan_info",
+    "sfw_plan_shared_prefix",
     "sfw_set_timing",
     "sfw_last_launch_ms",
     "sfw_grid_points",

@@ -297,10 +297,59 @@ double step_cost(double items, double items_per_wave) {
   return x <= 1.0 ? 0.45 + 0.55 * x : x;
 }
 
+// Everything plan_prefix derives from the staged sample vectors alone (no device involved).
+struct prefix_classes {
+  std::vector<std::vector<int32_t>> rc, cc;  // row / column classes per number of compared steps
+  std::vector<int32_t> nr, nc;               // class counts
+  int max_p = 0;
+  // a level past the last computed one has every value in its own class
+  const std::vector<int32_t> &rows_at(int p) const { return rc[std::min<size_t>(static_cast<size_t>(p), rc.size()) - 1]; }
+  const std::vector<int32_t> &cols_at(int p) const { return cc[std::min<size_t>(static_cast<size_t>(p), cc.size()) - 1]; }
+  int32_t n_rows_at(int p) const { return nr[std::min<size_t>(static_cast<size_t>(p), nr.size()) - 1]; }
+  int32_t n_cols_at(int p) const { return nc[std::min<size_t>(static_cast<size_t>(p), nc.size()) - 1]; }
+};
+
+prefix_classes classes_of_grid(const std::vector<double> &lin, const std::vector<double> &ang, double vx0, double vth0,
+                               double acc_x, double acc_theta, double dt, int S) {
+  prefix_classes pc;
+  pc.max_p = std::min(S - 1, 48);
+  velocity_classes(lin, vx0, acc_x, dt, pc.max_p, pc.rc, pc.nr);
+  velocity_classes(ang, vth0, acc_theta, dt, pc.max_p, pc.cc, pc.nc);
+  return pc;
+}
+
+// The levels' end steps.  A level ending at step p costs (p - q) steps over classes(p) items plus a
+// launch and the class records (0.4 to 1.0 of a round); the suffix costs (S - p) steps over all
+// samples.  Dynamic programme over the end step of the last level; empty when sharing does not pay.
+std::vector<int> choose_levels(const prefix_classes &pc, int64_t T, int S, double samples_per_wave) {
+  std::vector<int> steps;
+  const double full = step_cost(static_cast<double>(T), samples_per_wave);
+  const int last_p = std::min<int>(pc.max_p, static_cast<int>(std::max(pc.nr.size(), pc.nc.size())));
+  std::vector<double> best(static_cast<size_t>(last_p) + 1, 0.0);
+  std::vector<int> from(static_cast<size_t>(last_p) + 1, 0);
+  double best_total = S * full;
+  int best_end = 0;
+  for (int p = 1; p <= last_p; ++p) {
+    const double c = step_cost(static_cast<double>(pc.n_rows_at(p)) * pc.n_cols_at(p), samples_per_wave);
+    // per extra launch: dispatch + class records for an under-filled level; a level that fills the GPU
+    // also pays its ramp-up and tail (measured: 0.4 / 1.0 pick the fastest plans at cfg2 / target)
+    const double launch_cost = c < 1.0 ? 0.4 : 1.0;
+    best[p] = 1e300;
+    for (int q = 0; q < p; ++q) {
+      const double v = best[q] + (p - q) * c + launch_cost;
+      if (v < best[p]) { best[p] = v; from[p] = q; }
+    }
+    const double total = best[p] + (S - p) * full;
+    if (total < best_total) { best_total = total; best_end = p; }
+  }
+  if (best_total > 0.97 * S * full) return steps;  // not worth the extra launches
+  for (int p = best_end; p > 0; p = from[p]) steps.push_back(p);
+  std::reverse(steps.begin(), steps.end());
+  return steps;
+}
+
 // Decide the levels of the staged grid's shared-prefix tree and lay the class tables out per chunk of
-// whole rows.  A level ending at step p costs (p - q) steps over classes(p) items plus a launch and
-// the class records (0.4 to 1.0 of a round); the suffix costs (S - p) steps over all samples.  Dynamic
-// programme over the end step of the last level.
+// whole rows.
 int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   h->prefix_steps.clear();
   h->prefix_chunks.clear();
@@ -311,13 +360,10 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   if (!forced && T < 4096) return SFW_OK;  // the GPU is not full: extra launches cost more than they save
   const int64_t rows_per_chunk = chunk / h->nw;
   if (rows_per_chunk < 1) return SFW_OK;  // a single row does not fit the table budget: no sharing
-  const double dt = h->params.sim_time / S;
-  const int max_p = std::min(S - 1, 48);
-  std::vector<std::vector<int32_t>> rc, cc;
-  std::vector<int32_t> nr, nc;
-  velocity_classes(h->h_lin, h->rs.vx, h->ga.acc_x, dt, max_p, rc, nr);
-  velocity_classes(h->h_ang, h->rs.vtheta, h->ga.acc_theta, dt, max_p, cc, nc);
-  // a level past the last computed one has every value in its own class
+  const prefix_classes pc = classes_of_grid(h->h_lin, h->h_ang, h->rs.vx, h->rs.vtheta, h->ga.acc_x, h->ga.acc_theta,
+                                            h->params.sim_time / S, S);
+  const std::vector<std::vector<int32_t>> &rc = pc.rc, &cc = pc.cc;
+  const std::vector<int32_t> &nr = pc.nr, &nc = pc.nc;
   auto level = [](const std::vector<std::vector<int32_t>> &c, int p) -> const std::vector<int32_t> & {
     return c[std::min<size_t>(static_cast<size_t>(p), c.size()) - 1];
   };
@@ -325,31 +371,9 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   std::vector<int> steps;
   if (forced) {
     for (int p : h->prefix_env)
-      if (p >= 1 && p <= max_p) steps.push_back(p);
+      if (p >= 1 && p <= pc.max_p) steps.push_back(p);
   } else {
-    const double per_wave = static_cast<double>(sfw_samples_per_wave(h->st_A, std::min<int64_t>(T, rows_per_chunk * h->nw)));
-    const double full = step_cost(static_cast<double>(T), per_wave);
-    const int last_p = std::min<int>(max_p, static_cast<int>(std::max(nr.size(), nc.size())));
-    std::vector<double> best(static_cast<size_t>(last_p) + 1, 0.0);
-    std::vector<int> from(static_cast<size_t>(last_p) + 1, 0);
-    double best_total = S * full;
-    int best_end = 0;
-    for (int p = 1; p <= last_p; ++p) {
-      const double c = step_cost(static_cast<double>(count_at(nr, p)) * count_at(nc, p), per_wave);
-      // per extra launch: dispatch + class records for an under-filled level; a level that fills the GPU
-      // also pays its ramp-up and tail (measured: 0.4 / 1.0 pick the fastest plans at cfg2 / target)
-      const double launch_cost = c < 1.0 ? 0.4 : 1.0;
-      best[p] = 1e300;
-      for (int q = 0; q < p; ++q) {
-        const double v = best[q] + (p - q) * c + launch_cost;
-        if (v < best[p]) { best[p] = v; from[p] = q; }
-      }
-      const double total = best[p] + (S - p) * full;
-      if (total < best_total) { best_total = total; best_end = p; }
-    }
-    if (best_total > 0.97 * S * full) return SFW_OK;  // not worth the extra launches
-    for (int p = best_end; p > 0; p = from[p]) steps.push_back(p);
-    std::reverse(steps.begin(), steps.end());
+    steps = choose_levels(pc, T, S, static_cast<double>(sfw_samples_per_wave(h->st_A, std::min<int64_t>(T, rows_per_chunk * h->nw))));
   }
   if (steps.empty()) return SFW_OK;
   const size_t n_lv = steps.size();
@@ -913,6 +937,26 @@ int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp, doubl
   }
   h->staged = false;  // score_one clobbers the staged grid
   h->launched = false;
+  return SFW_OK;
+}
+
+int sfw_plan_shared_prefix(const double *linvels, int32_t nv, const double *angvels, int32_t nw, double vx0, double vtheta0,
+                           double acc_x, double acc_theta, double sim_time, int32_t num_steps, int32_t n_agents,
+                           int32_t *level_ends, int64_t *level_classes, int32_t cap, int32_t *n_levels) {
+  if (!linvels || !angvels || nv <= 0 || nw <= 0 || num_steps < 1 || !n_levels || cap < 0 ||
+      (cap > 0 && (!level_ends || !level_classes)))
+    return SFW_ERR_INVALID_ARG;
+  *n_levels = 0;
+  const int64_t T = static_cast<int64_t>(nv) * nw;
+  if (n_agents < 2 || num_steps < 2 || T < 4096) return SFW_OK;
+  const std::vector<double> lin(linvels, linvels + nv), ang(angvels, angvels + nw);
+  const prefix_classes pc = classes_of_grid(lin, ang, vx0, vtheta0, acc_x, acc_theta, sim_time / num_steps, num_steps);
+  const std::vector<int> steps = choose_levels(pc, T, num_steps, static_cast<double>(sfw_samples_per_wave(n_agents, T)));
+  *n_levels = static_cast<int32_t>(steps.size());
+  for (size_t l = 0; l < steps.size() && l < static_cast<size_t>(cap); ++l) {
+    level_ends[l] = steps[l];
+    level_classes[l] = static_cast<int64_t>(pc.n_rows_at(steps[l])) * pc.n_cols_at(steps[l]);
+  }
   return SFW_OK;
 }
 

@@ -1,0 +1,101 @@
+"""Host-side planning of the shared-prefix rollout (sfw_plan_shared_prefix: no handle, no device):
+the class counts against an independent Python restatement of the reference's velocity recurrence
+(sfw_planner.hpp:457-463), and the shape of the chosen levels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from social_force_window_planner_amd import planner
+from social_force_window_planner_amd import synthetic as syn
+
+
+def _lib():
+    L = planner.lib()
+    L.sfw_plan_shared_prefix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                         C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.POINTER(C.c_int32)]
+    L.sfw_plan_shared_prefix.restype = C.c_int
+    return L
+
+
+def _plan(lin, ang, vx0, vth0, acc_x, acc_th, sim_time, S, A, cap=64):
+    lin, ang = np.ascontiguousarray(lin, dtype=np.float64), np.ascontiguousarray(ang, dtype=np.float64)
+    ends = np.zeros(cap, dtype=np.int32)
+    classes = np.zeros(cap, dtype=np.int64)
+    n = C.c_int32(-1)
+    rc = _lib().sfw_plan_shared_prefix(lin.ctypes.data, len(lin), ang.ctypes.data, len(ang), vx0, vth0, acc_x, acc_th,
+                                       sim_time, S, A, ends.ctypes.data, classes.ctypes.data, cap, C.byref(n))
+    assert rc == 0
+    return [int(v) for v in ends[:n.value]], [int(v) for v in classes[:n.value]]
+
+
+def _new_velocity(vg, vi, a_max, dt):  # reference sfw_planner.hpp:457-463
+    if (vg - vi) >= 0:
+        return min(vg, vi + a_max * dt)
+    return max(vg, vi - a_max * dt)
+
+
+def _n_classes(targets, v0, a_max, dt, p):
+    """Distinct sequences of the first p velocities (bit patterns)."""
+    seqs = set()
+    for vg in targets:
+        v, seq = v0, []
+        for _ in range(p):
+            v = _new_velocity(float(vg), v, a_max, dt)
+            seq.append(np.float64(v).tobytes())
+        seqs.add(tuple(seq))
+    return len(seqs)
+
+
+@pytest.mark.parametrize("name", ["cfg2", "target"])
+def test_class_counts_match_the_recurrence(name):
+    w = syn.WORKLOADS[name]
+    scene = syn.make_scene(w)
+    vx0, vth0 = scene.robot_state[3], scene.robot_state[5]
+    acc_x, _, acc_th = scene.goal_args[0], scene.goal_args[1], scene.goal_args[2]
+    S = w.n_steps
+    ends, classes = _plan(scene.linvels, scene.angvels, vx0, vth0, acc_x, acc_th, w.sim_time, S, w.n_people + 1)
+    assert len(ends) >= 1 and ends == sorted(set(ends)) and 1 <= ends[0] and ends[-1] < S
+    assert classes == sorted(classes) and classes[-1] <= w.nv * w.nw
+    dt = w.sim_time / S
+    for p, n in zip(ends, classes):
+        assert n == _n_classes(scene.linvels, vx0, acc_x, dt, p) * _n_classes(scene.angvels, vth0, acc_th, dt, p)
+    # sharing has to remove a real part of the step x samples product
+    shared = sum(n * (p - q) for n, p, q in zip(classes, ends, [0] + ends[:-1]))
+    assert shared < 0.7 * w.nv * w.nw * ends[-1]
+
+
+def test_small_grids_and_single_agents_do_not_share():
+    lin, ang = syn.reference_sampler()
+    assert _plan(lin, ang, 0.3, 0.0, 1.0, 1.0, 1.0, 40, 6) == ([], [])  # 45 samples: the GPU is not full
+    lin, ang = syn.generalised_sampler(128, 128)
+    assert _plan(lin, ang, 0.3, 0.0, 1.0, 1.0, 1.0, 40, 1) == ([], [])  # robot only: K2 has nothing to integrate twice
+    assert _plan(lin, ang, 0.3, 0.0, 1.0, 1.0, 0.025, 1, 21) == ([], [])  # a single step
+
+
+def test_degenerate_windows():
+    lin, ang = syn.generalised_sampler(64, 64)
+    # no acceleration at all: every sample keeps the current velocity for ever -> one class, one level to the end
+    ends, classes = _plan(lin, ang, 0.3, 0.0, 0.0, 0.0, 1.0, 40, 21)
+    assert ends == [39] and classes == [1]
+    # unlimited acceleration: every sample reaches its own target in the first step -> nothing to share
+    assert _plan(lin, ang, 0.3, 0.0, 1e6, 1e6, 1.0, 40, 21) == ([], [])
+    # duplicate targets never separate
+    lin2 = np.concatenate([lin, lin])
+    ends, classes = _plan(lin2, ang, 0.3, 0.0, 1e6, 1e6, 1.0, 40, 21)
+    assert ends == [39] and classes == [64 * 64]
+    # long horizons: levels end within the first 48 steps
+    ends, _ = _plan(lin, ang, 0.3, 0.0, 0.05, 0.05, 10.0, 400, 21)
+    assert ends and ends[-1] <= 48
+
+
+def test_argument_errors():
+    n = C.c_int32(0)
+    lin, ang = syn.generalised_sampler(64, 64)
+    L = _lib()
+    assert L.sfw_plan_shared_prefix(None, 64, ang.ctypes.data, 64, 0.0, 0.0, 1.0, 1.0, 1.0, 40, 5, None, None, 0, C.byref(n)) < 0
+    assert L.sfw_plan_shared_prefix(lin.ctypes.data, 64, ang.ctypes.data, 64, 0.0, 0.0, 1.0, 1.0, 1.0, 0, 5, None, None, 0, C.byref(n)) < 0
+    # cap = 0: only the number of levels is reported
+    assert L.sfw_plan_shared_prefix(lin.ctypes.data, 64, ang.ctypes.data, 64, 0.3, 0.0, 1.0, 1.0, 1.0, 40, 21, None, None, 0, C.byref(n)) == 0
+    assert n.value >= 1
