@@ -231,8 +231,9 @@ def roofline_for(job, k2_ms, precision):
         "unit": "TFLOP/s",
         "frac": ach / peak,
         "traffic": tr["k2_bytes"] if tr else None,
-        "traffic_note": ("HBM bytes per K2 launch, rocprofv3 PMC passes committed in profiles/r01_traffic.json "
-                         "(the K1->K2 robot-step table; algorithmic bytes are in roofline.hbm)") if tr else None,
+        "traffic_note": ("HBM bytes per step through all K2 dispatches, rocprofv3 PMC passes committed in "
+                         "profiles/r01_traffic.json (the K1->K2 robot-step table and the class records of the "
+                         "shared-prefix levels; algorithmic bytes are in roofline.hbm)") if tr else None,
         "flops_per_trajectory": flops_traj,
         "kernel_ms": k2_ms,
         "launches_per_step": job.plan["chunks"] * (1 + job.plan["levels"]),
@@ -244,7 +245,9 @@ def roofline_for(job, k2_ms, precision):
                                    "kernel_ms spans the prefix launches and the suffix launch, `achieved` still "
                                    "prices the full algorithmic work"} if job.plan["levels"] > 0 else None),
         "note": "algorithmic flops per SURVEY.md §8d (48 per ordered pair incl. exp/atan2/sqrt as 1 op each); "
-                "non-MFMA vector peak for the dtype",
+                "non-MFMA vector peak for the dtype (the path is FP64 vector-ALU bound, neither HBM nor MFMA); "
+                "kernel_ms = HIP events from the end of the pose rollout (K1a) to the end of the last K2 dispatch, "
+                "i.e. all K2 dispatches of a step incl. the footprint/costmap kernels that run beside the prefix levels",
         "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                 "traffic": tr["all_kernels_bytes"] if tr else None, "bytes_per_launch": bytes_launch,
                 "note": "non-binding by construction: a few bytes per trajectory (SURVEY.md §8d)"},
