@@ -79,3 +79,23 @@ def test_product_does_not_link_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libsfw_oracle" not in src, f
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/sfw_hip.h is the drop-in boundary: it has to compile as C (a cgo / JNI / ctypes binding sees
+    nothing else), with every declared function callable from a C translation unit."""
+    import os
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "sfw_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(sfw_[a-z_0-9]+)\s*\(", header)))
+    assert set(names) == set(EXPORTED_SYMBOLS)
+    src = tmp_path / "abi_check.c"
+    src.write_text('#include "sfw_hip.h"\n'
+                   + "".join(f"void *use_{n}(void) {{ return (void *){n}; }}\n" for n in names)
+                   + "int main(void) { sfw_params p; sfw_params_default(&p); return (int)sizeof(sfw_agent) + (int)sizeof(sfw_plan_info); }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Wno-pedantic", "-I", os.path.join(root, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
