@@ -22,3 +22,15 @@ def test_robot_crosses_the_room(args):
     assert r.returncode == 0 and reached == 1 and dist < 0.1 + 1e-9   # inside xy_goal_tolerance
     assert clear > 0.35                                               # never inside the robot radius of a person
     assert failed <= cycles // 100
+
+
+def test_plain_c_caller():
+    """examples/minimal_c.c: the C ABI from a C99 translation unit, one control cycle."""
+    csrc = os.path.join(ROOT, "social_force_window_planner_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "cdemo"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(ROOT, "build", "minimal_c")], capture_output=True, text=True, timeout=120)
+    m = re.search(r"RESULT index=(-?\d+) vx=([\d.]+) vtheta=(-?[\d.]+) cost=([\d.]+) valid=(\d+)", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-2000:] + r.stderr[-2000:]
+    assert int(m[1]) >= 0 and int(m[5]) >= 1 and float(m[4]) >= 0.0
+    assert "-2.000" in r.stdout  # the never-scored (0,0) sample
