@@ -576,42 +576,47 @@ __device__ __forceinline__ agent_k agent_k_global(const sfw_launch &L, int i) {
 
 // lightsfm computeGroupForce (non-_PAPER_VERSION_ branch)
 // for agent i of sample g at position (px,py): gaze + coherence + repulsion.
-// Group centres (sums of member positions) must already be in s.gcen.  Rare
-// path: plain IEEE sqrt/div/acos/tanh, in double in both precision modes.
+// Group centres (sums of member positions) must already be in s.gcen.  Double in
+// both precision modes, written like the pair term — no library calls:
+//   * gaze fires when acos(dir . rel / (|dir||rel|)) > 90 deg, i.e. when dir . rel < 0 (no acos; the two
+//     tests differ only for a cosine in (-1.6e-16, 0), where acos rounds to pi/2);
+//   * (tanh(x) + 1) / 2 = 1 / (1 + exp(-2x));
+//   * |d| < ra + rb is tested as |d|^2 < (ra + rb)^2.
 template <typename R>
 __device__ double2 group_force(const sfm_consts<R> &k, const lds_layout &s, int NG, int g, int A, int i, int sl,
                                double px, double py) {
   const int q = s.grp[i];
   if (q < 0) return double2{0.0, 0.0};
   const int m0 = s.goff[q], m1 = s.goff[q + 1];
-  const double n = static_cast<double>(m1 - m0);
   if (m1 - m0 < 2) return double2{0.0, 0.0};
+  const double n = static_cast<double>(m1 - m0), inv_n = sfwm::rcp_nr(n);
   const double2 csum = s.gcen[g * NG + q];
-  const double cx = csum.x / n, cy = csum.y / n;
+  const double cx = csum.x * inv_n, cy = csum.y * inv_n;
   // desired direction at this state (zero when the agent has no goal to walk to)
   const double2 gl = s.goal[i];
   const double ex = gl.x - px, ey = gl.y - py;
-  const double en = sqrt(ex * ex + ey * ey);
-  double ddx = 0.0, ddy = 0.0;
-  if (s.hasgoal[sl] && en > s.gr[i] && en > 0.0) { ddx = ex / en; ddy = ey / en; }
+  double inv_en, en;
+  sfwm::rsqrt_sqrt(fmax(fma(ex, ex, ey * ey), 1e-300), inv_en, en);
+  const bool has_dir = s.hasgoal[sl] && en > s.gr[i];
+  const double ddx = has_dir ? ex * inv_en : 0.0, ddy = has_dir ? ey * inv_en : 0.0;
   double fx = 0.0, fy = 0.0;
-  {  // gaze
-    const double w = 1.0 / (n - 1.0);
-    const double rx = w * (n * cx - px) - px, ry = w * (n * cy - py) - py;
-    const double ep = ddx * rx + ddy * ry;
-    const double ang = acos(ep / (sqrt(ddx * ddx + ddy * ddy) * sqrt(rx * rx + ry * ry)));
-    if (ang > 90.0 * M_PI / 180.0) {  // NaN (no desired direction) compares false
-      const double sc = k.f_gaze * (ep / (ddx * ddx + ddy * ddy));
+  {  // gaze: pulls along the desired direction when the rest of the group is behind
+    const double w = sfwm::rcp_nr(n - 1.0);
+    const double rx = fma(w, fma(n, cx, -px), -px), ry = fma(w, fma(n, cy, -py), -py);
+    const double ep = fma(ddx, rx, ddy * ry);
+    if (ep < 0.0) {  // has_dir is implied: ep == 0 without a direction
+      const double sc = k.f_gaze * ep;  // (ep / |dir|^2) dir with |dir| = 1
       fx = sc * ddx;
       fy = sc * ddy;
     }
   }
   {  // coherence
     const double rx = cx - px, ry = cy - py;
-    const double dist = sqrt(rx * rx + ry * ry);
-    const double soft = k.f_coherence * (tanh(dist - (n - 1.0) / 2.0) + 1.0) / 2.0;
-    fx += rx * soft;
-    fy += ry * soft;
+    const double dist = fast_norm(rx, ry);
+    const double x2 = fmin(2.0 * ((n - 1.0) * 0.5 - dist), 700.0);  // -2 (dist - maxd)
+    const double soft = k.f_coherence * sfwm::rcp_nr(1.0 + sfwm::exp_fast(k.pc, x2));
+    fx = fma(rx, soft, fx);
+    fy = fma(ry, soft, fy);
   }
   double rx = 0.0, ry = 0.0;  // repulsion between overlapping members
   const double ra = s.rad[i];
@@ -619,11 +624,11 @@ __device__ double2 group_force(const sfm_consts<R> &k, const lds_layout &s, int 
     const int b = s.gmem[m];
     if (b == i) continue;
     const double2 pb = s.pos[g * A + b];
-    const double dx = px - pb.x, dy = py - pb.y;
-    if (sqrt(dx * dx + dy * dy) < ra + s.rad[b]) { rx += dx; ry += dy; }
+    const double dx = px - pb.x, dy = py - pb.y, rr = ra + s.rad[b];
+    if (fma(dx, dx, dy * dy) < rr * rr) { rx += dx; ry += dy; }
   }
-  fx += rx * k.f_repulsion;
-  fy += ry * k.f_repulsion;
+  fx = fma(rx, k.f_repulsion, fx);
+  fy = fma(ry, k.f_repulsion, fy);
   return double2{fx, fy};
 }
 
