@@ -3,7 +3,7 @@
 // whole-cycle medians of  set_costmap + set_footprint + set_agents + score_grid (blocking).
 //
 //   build: make -C social_force_window_planner_amd/csrc latency
-//   run:   build/cycle_latency [cycles]
+//   run:   build/cycle_latency [cycles] [laser points]
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -24,6 +24,13 @@ static double median(std::vector<double> v) {
 
 int main(int argc, char **argv) {
   const int cycles = argc > 1 ? std::atoi(argv[1]) : 200;
+  const int n_laser = argc > 2 ? std::atoi(argv[2]) : 0;  // obstacles1: laser points near the robot
+  std::vector<double> laser;
+  for (int i = 0; i < n_laser; ++i) {  // a wall 1.5 m to the left and a pillar ahead
+    const double u = (i + 0.5) / n_laser;
+    if (i % 3) { laser.push_back(-2.0 + 5.0 * u); laser.push_back(1.5); }
+    else { laser.push_back(2.5 + 0.2 * std::cos(9.0 * u)); laser.push_back(-1.0 + 0.2 * std::sin(9.0 * u)); }
+  }
   const unsigned N = 200;
   const double res = 0.05, origin = -5.0;
   std::vector<uint8_t> cells(static_cast<size_t>(N) * N, 0);
@@ -70,7 +77,7 @@ int main(int argc, char **argv) {
         const double a = us_since(t0);
         rc |= sfw_set_footprint(h, fp.data(), 16);
         const double b = us_since(t0);
-        rc |= sfw_set_agents(h, ag.data(), static_cast<int>(ag.size()), nullptr, 0);
+        rc |= sfw_set_agents(h, ag.data(), static_cast<int>(ag.size()), n_laser ? laser.data() : nullptr, n_laser);
         const double d = us_since(t0);
         rc |= sfw_score_grid(h, &rs, lin, 5, ang, 9, &ga, costs.data(), &best);
         const double e = us_since(t0);
@@ -82,8 +89,8 @@ int main(int argc, char **argv) {
           t_map.push_back(a); t_fp.push_back(b - a); t_ag.push_back(d - b); t_score.push_back(e - d); t_all.push_back(e);
         }
       }
-      std::printf("N=%2d S=%2d: cycle %6.1f us  (set_costmap %5.1f  set_footprint %4.1f  set_agents %5.1f  score_grid %6.1f)  best index %lld\n",
-                  n_people, static_cast<int>(p.sim_time / p.sim_granularity + 0.5), median(t_all), median(t_map),
+      std::printf("N=%2d O=%3d S=%2d: cycle %6.1f us  (set_costmap %5.1f  set_footprint %4.1f  set_agents %5.1f  score_grid %6.1f)  best index %lld\n",
+                  n_people, n_laser, static_cast<int>(p.sim_time / p.sim_granularity + 0.5), median(t_all), median(t_map),
                   median(t_fp), median(t_ag), median(t_score), static_cast<long long>(best.index));
       sfw_destroy(h);
     }
