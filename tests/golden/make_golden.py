@@ -50,6 +50,23 @@ def blocked_scene(seed):
     return sc
 
 
+def grouped_scene(seed):
+    """Two walking groups (3 and 2 members, distinct speeds: exact relative rest is the one input class on
+    which the reference's sign(theta) is rounding noise), a singleton group, 6 laser points."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=6, nw=7, n_people=11, seed=seed, n_obstacles=6)
+    sc = syn.make_scene(w)
+    ag = sc.agents
+    for gid, members in ((3, (1, 2, 3)), (8, (5, 6))):
+        lead = ag[members[0]]
+        for k, m in enumerate(members):
+            ag[m].group_id = gid
+            ag[m].x, ag[m].y = lead.x + 0.45 * k, lead.y + 0.3 * k
+            ag[m].vx, ag[m].vy = lead.vx * (1.0 + 0.03 * k) + 0.01 * k, lead.vy * (1.0 - 0.02 * k)
+            ag[m].goal_x, ag[m].goal_y = ag[m].x + 2.0 * ag[m].vx, ag[m].y + 2.0 * ag[m].vy
+    ag[9].group_id = 40  # a group of one: no group force
+    return sc
+
+
 def cases():
     yield "cfg1", syn.make_scene("cfg1"), {}
     for n in (0, 1, 5):
@@ -60,6 +77,7 @@ def cases():
     w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=6, nw=7, n_people=70, seed=22, footprint="point")
     yield "crowd70_point", syn.make_scene(w), {}
     yield "blocked", blocked_scene(23), {}
+    yield "groups_obs", grouped_scene(25), {}
     w = dataclasses.replace(syn.WORKLOADS["cfg3"], nv=5, nw=6, map_size=200, seed=24)
     yield "cfg3_5x6_yamlweights", syn.make_scene(w), dict(social_weight=2.0, vel_weight=0.8, angle_weight=0.6,
                                                           max_vel_x=0.8, robot_radius=0.4)
