@@ -2,14 +2,22 @@
 """bench.py — scored trajectories/s of the DWA rollout + social-force scoring
 path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target]
 
-One "step" = one pass of the hot path over one (v,w) grid: rollout+costmap
-kernel, social-force kernel, argmin kernels and the 48-byte D2H of the selected
-command, with every input (costmap, agents, sample vectors) already resident in
-HBM.  N > 1 (one process per GPU under torch.distributed.run): the linvel rows
-of an N-times larger grid are sharded over the ranks (weak scaling, SURVEY.md
-§8e) and one all-reduce(min) per step picks the global best.
+One "step" = one BLOCKING scoring call through the C ABI, as SURVEY.md §8d defines the
+metric (the reference's grid loop is one blocking loop, src/sfw_planner.cpp:345-417):
+sfw_grid_stage (shared-prefix planning on the host + ONE H2D copy of footprint, agents and
+the sample vectors) + sfw_grid_launch (K1a/K1b/K1c, the K2 dispatches, K3) + sfw_grid_fetch
+(D2H of the 8*T-byte cost vector and the selection, stream sync) — the three calls
+sfw_score_grid is made of.  The world state (costmap, footprint, agents) is resident in the
+library before the timed region starts.  Default workload: the north-star target
+configuration (256 x 256 samples, 50 pedestrians, 40 steps).
+
+N > 1 (one process per GPU under torch.distributed.run): every rank scores one
+workload-sized block of linvel rows of an N-times taller grid (weak scaling; rows are the
+outer, sharded axis, ref :345) and one all-reduce(min) of the [N,4] f64 key table per step
+picks the global best.  Every N also reports BASELINE.json config 5 (4096 x 4096, 100
+pedestrians) sharded over the N ranks under extra.cfg5_strong (strong scaling).
 
 Rank 0 prints ONE JSON line.
 """
@@ -32,23 +40,28 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # AMD MI355X datasheet
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md
 
-
 GRID_OVERRIDE = None
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", help="BASELINE.json config: cfg1..cfg5, target, ref5x9")
+    ap.add_argument("--workload", default="target",
+                    help="BASELINE.json config: target (default), cfg1..cfg5, cfg2_o64, ref5x9")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (target-config) measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads under `extra`")
+    ap.add_argument("--extras", default="cfg5_strong,upload,resident,cfg2,cfg2_o64,cfg3,cfg4,f32",
+                    help="comma-separated secondary measurements to run (all by default)")
+    ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each secondary workload")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (gloo: CPU tensors; lets several ranks share one GPU in tests)")
     ap.add_argument("--grid", default=None, help="override the sample grid, e.g. 512x512 (experiments only)")
     ap.add_argument("--verify", action="store_true", help="check the GPU result against the oracle on a sample subset")
+    ap.add_argument("--resident", action="store_true",
+                    help="time launch + selection fetch only (no stage, no cost-vector D2H): kernel tuning aid")
     return ap.parse_args()
 
 
@@ -62,23 +75,28 @@ def cpu_baseline(scene, params_kw, budget_s=12.0):
     o = OracleScorer(default_params(**params_kw))
     o.load_scene(scene)
     lin, ang = scene.linvels, scene.angvels
-    # calibrate on one row
+    cols = ang
+    # calibrate on a slice of one row
+    ncal = min(len(ang), 16)
     t0 = time.perf_counter()
-    o.score_grid(scene.robot_state, lin[-1:], ang, scene.goal_args, n_threads=1)
-    per_traj = (time.perf_counter() - t0) / len(ang)
-    rows = int(max(1, min(len(lin), budget_s / 2 / max(per_traj * len(ang), 1e-9))))
+    o.score_grid(scene.robot_state, lin[-1:], ang[:ncal], scene.goal_args, n_threads=1)
+    per_traj = (time.perf_counter() - t0) / ncal
+    if per_traj * len(ang) > budget_s / 2:  # a whole row would blow the budget: evenly spaced columns instead
+        ncol = int(max(8, min(len(ang), budget_s / 2 / per_traj)))
+        cols = ang[np.unique(np.linspace(0, len(ang) - 1, ncol).round().astype(int))]
+    rows = int(max(1, min(len(lin), budget_s / 2 / max(per_traj * len(cols), 1e-9))))
     sel = np.unique(np.linspace(0, len(lin) - 1, rows).round().astype(int))
     sub = lin[sel]
-    n = len(sub) * len(ang)
+    n = len(sub) * len(cols)
     t0 = time.perf_counter()
-    o.score_grid(scene.robot_state, sub, ang, scene.goal_args, n_threads=1)
+    o.score_grid(scene.robot_state, sub, cols, scene.goal_args, n_threads=1)
     t1 = time.perf_counter() - t0
     cores = olib().sfwo_max_threads()
     rows_mt = int(max(1, min(len(lin), rows * max(1, cores // 2))))
     sel_mt = np.unique(np.linspace(0, len(lin) - 1, rows_mt).round().astype(int))
     sub_mt = lin[sel_mt]
     t0 = time.perf_counter()
-    o.score_grid(scene.robot_state, sub_mt, ang, scene.goal_args, n_threads=cores)
+    o.score_grid(scene.robot_state, sub_mt, cols, scene.goal_args, n_threads=cores)
     tm = time.perf_counter() - t0
     cpu_model = ""
     try:
@@ -94,18 +112,20 @@ def cpu_baseline(scene, params_kw, budget_s=12.0):
         "unit": "trajectories/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{len(sub)} of {len(lin)} linvel rows x {len(ang)} angvels = {n} trajectories, oracle -O2 double, 1 thread",
-        "all_cores": {"value": len(sub_mt) * len(ang) / tm, "cores": cores,
-                      "sample": f"{len(sub_mt)} rows x {len(ang)} = {len(sub_mt) * len(ang)} trajectories, OpenMP"},
+        "sample": f"{len(sub)} of {len(lin)} linvel rows x {len(cols)} of {len(ang)} angvels = {n} trajectories, "
+                  f"oracle -O2 double, 1 thread",
+        "all_cores": {"value": len(sub_mt) * len(cols) / tm, "cores": cores,
+                      "sample": f"{len(sub_mt)} rows x {len(cols)} = {len(sub_mt) * len(cols)} trajectories, OpenMP"},
         "cpu_model": cpu_model,
         "nproc": os.cpu_count(),
     }
 
 
 class GridJob:
-    """One rank's share of a workload, resident on its GPU."""
+    """One rank's share of a workload, world state resident on its GPU."""
 
-    def __init__(self, workload_name, precision, rank, world, device):
+    def __init__(self, workload_name, precision, rank, world, device, scaling="weak"):
+        from social_force_window_planner_amd import multi_gpu
         from social_force_window_planner_amd import synthetic as syn
         from social_force_window_planner_amd._abi import SFW_PRECISION_F32, SFW_PRECISION_F64, default_params
         from social_force_window_planner_amd.planner import HipScorer
@@ -114,20 +134,22 @@ class GridJob:
         if GRID_OVERRIDE:
             nv, nw = (int(v) for v in GRID_OVERRIDE.lower().split("x"))
             w = dataclasses.replace(w, nv=nv, nw=nw)
-        if world > 1:  # weak scaling: N-times more linvel rows, this rank takes its block
+        if world > 1 and scaling == "weak":  # N-times more linvel rows, this rank takes its block
             w = dataclasses.replace(w, nv=w.nv * world)
         self.workload = w
-        self.scene = syn.make_scene(w)
+        # the scene (costmap, people) does not depend on the grid size: build it with a small grid and
+        # sample the full grid separately (cfg5's 4096-row vectors are only sliced here)
+        self.scene = syn.make_scene(w if w.sampler == "reference" else dataclasses.replace(w, nv=2, nw=2))
+        lin_all, ang = syn.generalised_sampler(w.nv, w.nw) if w.sampler != "reference" else syn.reference_sampler()
+        self.lin_all = lin_all
         self.params_kw = dict(sim_time=w.sim_time, sim_granularity=w.sim_granularity)
         prec = SFW_PRECISION_F32 if precision == "f32" else SFW_PRECISION_F64
         self.scorer = HipScorer(default_params(precision=prec, **self.params_kw), device=device)
-        self.scorer.set_timing(True)  # per-kernel HIP events for the roofline object
+        self.scorer.set_timing(True)  # per-kernel HIP events (on the handle's stream) for the roofline object
         self.scorer.load_scene(self.scene)
-        from social_force_window_planner_amd import multi_gpu
-
         self.row0, row1 = multi_gpu.shard_rows(w.nv, rank, world)
-        self.lin = self.scene.linvels[self.row0:row1]
-        self.ang = self.scene.angvels
+        self.lin = lin_all[self.row0:row1]
+        self.ang = ang
         self.index_base = self.row0 * len(self.ang)
         self.n_local = len(self.lin) * len(self.ang)
         zero = int(np.any(self.lin == 0.0) and np.any(self.ang == 0.0))
@@ -135,56 +157,75 @@ class GridJob:
         self.scorer.stage(self.scene.robot_state, self.lin, self.ang, self.scene.goal_args, self.index_base)
         self.plan = self.scorer.plan_info()
 
-    def step(self):
-        self.scorer.launch()
-        _, best, key = self.scorer.fetch(want_costs=False)
-        return best, key
+    def step(self, resident=False):
+        s, sc = self.scorer, self.scene
+        if resident:
+            s.launch()
+            return s.fetch(want_costs=False)
+        s.stage(sc.robot_state, self.lin, self.ang, sc.goal_args, self.index_base)
+        s.launch()
+        return s.fetch(want_costs=True)
 
 
-def run_single_config(workload_name, precision, steps, warmup, dist_ctx):
+def run_config(workload_name, precision, steps, warmup, ctx, scaling="weak", resident=False):
     import torch
 
-    rank, world, device = dist_ctx["rank"], dist_ctx["world"], dist_ctx["device"]
-    job = GridJob(workload_name, precision, rank, world, device)
-    dist = dist_ctx.get("dist")
+    rank, world, device = ctx["rank"], ctx["world"], ctx["device"]
+    job = GridJob(workload_name, precision, rank, world, device, scaling)
+    dist = ctx.get("dist")
     from social_force_window_planner_amd import multi_gpu
 
-    state = {"win": (0, None)}
+    state = {"win": (0, None), "xchg": []}
 
     def one_step():
-        best, key = job.step()
+        _, best, key = job.step(resident)
         if dist is not None:  # single all-reduce(min): every rank fills its own row, +inf elsewhere
-            wr, wk, _ = multi_gpu.exchange_best(key, dist, rank, world, device=dist_ctx["coll_device"])
+            t0 = time.perf_counter()
+            wr, wk, _ = multi_gpu.exchange_best(key, dist, rank, world, device=ctx["coll_device"])
+            state["xchg"].append(time.perf_counter() - t0)
             state["win"] = (wr, wk)
         return best, key
 
     for _ in range(warmup):
         one_step()
-    k2_ms, k1_ms, k3_ms, all_ms = [], [], [], []
+    state["xchg"].clear()
+    k2_ms, k1_ms, k3_ms, all_ms, wall = [], [], [], [], []
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    tp = t0
     for _ in range(steps):
         best, key = one_step()
-        # HIP events recorded on the handle's own stream around each kernel; the dominant
-        # kernel (K2) is read back on every timed step, the small ones on every 4th
+        # HIP events recorded on the handle's own stream around each kernel group
         k2_ms.append(job.scorer.last_launch_ms(2))
         if len(k2_ms) % 4 == 1:
             all_ms.append(job.scorer.last_launch_ms(0))
             k1_ms.append(job.scorer.last_launch_ms(1))
             k3_ms.append(job.scorer.last_launch_ms(3))
+        tn = time.perf_counter()
+        wall.append(tn - tp)
+        tp = tn
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dist_ctx["coll_device"])
+        cd = ctx["coll_device"]
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cd)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([float(job.n_scored)], dtype=torch.float64, device=dist_ctx["coll_device"])
+        tot = torch.tensor([float(job.n_scored)], dtype=torch.float64, device=cd)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         n_scored_total = int(tot.item())
+        mine = torch.zeros((world, 3), dtype=torch.float64, device=cd)
+        mine[rank] = torch.tensor([float(np.mean(k2_ms)), float(np.median(wall)) * 1e3,
+                                   float(np.median(state["xchg"])) * 1e6], dtype=torch.float64)
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        tab = mine.cpu().numpy()
+        per_rank = {"social_kernel_ms": tab[:, 0].tolist(), "median_step_ms": tab[:, 1].tolist(),
+                    "exchange_us": tab[:, 2].tolist()}
         win_rank, win_key = state["win"]
     else:
         n_scored_total = job.n_scored
@@ -192,7 +233,9 @@ def run_single_config(workload_name, precision, steps, warmup, dist_ctx):
     return {
         "job": job,
         "elapsed": elapsed,
+        "steps": steps,
         "n_scored_total": n_scored_total,
+        "median_step_ms": float(np.median(wall)) * 1e3,
         "k1_ms": float(np.mean(k1_ms)),
         "k2_ms": float(np.mean(k2_ms)),
         "k3_ms": float(np.mean(k3_ms)),
@@ -200,19 +243,26 @@ def run_single_config(workload_name, precision, steps, warmup, dist_ctx):
         "best": best,
         "global_key": win_key,
         "winner_rank": win_rank,
+        "per_rank": per_rank,
     }
 
 
 def measured_traffic(workload_name):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return json.load(f).get(workload_name)
-    except (OSError, ValueError):
-        return None
+    """HBM bytes per launch from the committed PMC passes (profiles/r0N_traffic.json, newest first), or None."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f).get(workload_name)
+            if d:
+                d = dict(d)
+                d["source"] = "profiles/" + name
+                return d
+        except (OSError, ValueError):
+            pass
+    return None
 
 
-def roofline_for(job, k2_ms, precision):
+def roofline_for(job, k2_ms, precision, brief=False):
     from social_force_window_planner_amd import synthetic as syn
 
     w = job.workload
@@ -220,6 +270,14 @@ def roofline_for(job, k2_ms, precision):
     flops_launch = flops_traj * job.n_scored
     peak = FP32_VECTOR_PEAK_TFLOPS if precision == "f32" else FP64_VECTOR_PEAK_TFLOPS
     ach = flops_launch / (k2_ms * 1e-3) / 1e12 if k2_ms > 0 else 0.0
+    # work actually integrated: class-steps of the shared-prefix levels + the samples' remaining steps
+    plan = job.plan
+    total_steps = plan["samples"] * w.n_steps
+    executed_steps = plan["class_steps"] + plan["samples"] * (w.n_steps - plan["split_step"]) if plan["levels"] > 0 \
+        else total_steps
+    executed_share = executed_steps / total_steps if total_steps else 1.0
+    if brief:
+        return {"frac": ach / peak, "executed_frac": ach / peak * executed_share, "achieved_tflops": ach}
     bytes_launch = syn.algorithmic_bytes_per_call(dataclasses.replace(w, nv=len(job.lin)), len(job.scene.footprint))
     hbm = bytes_launch / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
     tr = measured_traffic(job.workload.name) if (precision == "f64" and not GRID_OVERRIDE) else None
@@ -230,27 +288,54 @@ def roofline_for(job, k2_ms, precision):
         "peak": peak,
         "unit": "TFLOP/s",
         "frac": ach / peak,
+        "executed_frac": ach / peak * executed_share,
+        "executed_share_of_algorithmic_steps": executed_share,
         "traffic": tr["k2_bytes"] if tr else None,
         "traffic_note": ("HBM bytes per step through all K2 dispatches, rocprofv3 PMC passes committed in "
-                         "profiles/r01_traffic.json (the K1->K2 robot-step table and the class records of the "
-                         "shared-prefix levels; algorithmic bytes are in roofline.hbm)") if tr else None,
+                         + tr["source"] + " (algorithmic bytes are in roofline.hbm)") if tr else None,
         "flops_per_trajectory": flops_traj,
         "kernel_ms": k2_ms,
-        "launches_per_step": job.plan["chunks"] * (1 + job.plan["levels"]),
-        "shared_prefix": ({"split_step": job.plan["split_step"], "levels": job.plan["levels"],
-                           "class_steps": job.plan["class_steps"],
-                           "sample_steps_replaced": job.plan["samples"] * job.plan["split_step"],
-                           "note": "steps [0, split_step) are simulated along a tree of classes of samples whose "
-                                   "robot trajectories coincide under the acceleration limits (bit-identical costs); "
-                                   "kernel_ms spans the prefix launches and the suffix launch, `achieved` still "
-                                   "prices the full algorithmic work"} if job.plan["levels"] > 0 else None),
-        "note": "algorithmic flops per SURVEY.md §8d (48 per ordered pair incl. exp/atan2/sqrt as 1 op each); "
-                "non-MFMA vector peak for the dtype (the path is FP64 vector-ALU bound, neither HBM nor MFMA); "
-                "kernel_ms = HIP events from the end of the pose rollout (K1a) to the end of the last K2 dispatch, "
-                "i.e. all K2 dispatches of a step incl. the footprint/costmap kernels that run beside the prefix levels",
+        "launches_per_step": plan["chunks"] * (1 + plan["levels"]),
+        "shared_prefix": ({"split_step": plan["split_step"], "levels": plan["levels"],
+                           "class_steps": plan["class_steps"],
+                           "sample_steps_replaced": plan["samples"] * plan["split_step"]}
+                          if plan["levels"] > 0 else None),
+        "note": "frac: algorithmic flops per SURVEY.md §8d (48 per ordered pair incl. exp/atan2/sqrt as 1 op each) / "
+                "kernel_ms / non-MFMA vector peak of the dtype (the path is FP64 vector-ALU bound, neither HBM nor "
+                "MFMA).  executed_frac: the same with only the steps actually integrated (the shared-prefix rollout "
+                "simulates the first split_step steps once per class of samples with bit-identical robot "
+                "trajectories).  kernel_ms = HIP events on the handle's stream from the end of the pose rollout "
+                "(K1a) to the end of the last K2 dispatch",
         "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                 "traffic": tr["all_kernels_bytes"] if tr else None, "bytes_per_launch": bytes_launch,
                 "note": "non-binding by construction: a few bytes per trajectory (SURVEY.md §8d)"},
+    }
+
+
+def workload_text(w):
+    return (f"{w.name}: {w.nv}x{w.nw} (v,w) grid, {w.n_people} pedestrians, {w.map_size}x{w.map_size} costmap, "
+            f"sim_time={w.sim_time} s, sim_granularity={w.sim_granularity} ({w.n_steps} steps), 16-gon footprint"
+            + (f", {w.n_obstacles} laser points" if w.n_obstacles else ""))
+
+
+def extra_entry(name, precision, steps, warmup, ctx):
+    r = run_config(name, precision, steps, warmup, ctx)
+    j = r["job"]
+    rf = roofline_for(j, r["k2_ms"], precision, brief=True)
+    return {
+        "workload": workload_text(j.workload),
+        "value": r["n_scored_total"] * steps / r["elapsed"],
+        "unit": "trajectories/s",
+        "steps": steps,
+        "ms_per_step": r["elapsed"] / steps * 1e3,
+        "median_ms_per_step": r["median_step_ms"],
+        "kernel_only_value": j.n_scored / (r["launch_ms"] * 1e-3),
+        "kernel_ms": {"rollout": r["k1_ms"], "social": r["k2_ms"], "argmin": r["k3_ms"], "launch_total": r["launch_ms"]},
+        "roofline_frac": rf["frac"],
+        "roofline_executed_frac": rf["executed_frac"],
+        "chunks": j.plan["chunks"],
+        "cmd_vel_index": r["best"]["index"],
+        "n_valid": r["best"]["n_valid"],
     }
 
 
@@ -286,7 +371,7 @@ def main():
     ctx = {"rank": rank, "world": world, "device": local_rank, "dist": dist,
            "coll_device": f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"}
 
-    res = run_single_config(args.workload, args.precision, args.steps, args.warmup, ctx)
+    res = run_config(args.workload, args.precision, args.steps, args.warmup, ctx, resident=args.resident)
     job = res["job"]
     value = res["n_scored_total"] * args.steps / res["elapsed"]
     w = job.workload
@@ -298,21 +383,25 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": res["elapsed"] / args.steps * 1e3,
+        "median_ms_per_step": res["median_step_ms"],
+        "value_at_median": job.n_scored * world / (res["median_step_ms"] * 1e-3) if world == 1 else None,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": args.precision,
         "data": "synthetic (seeded costmap/people per SURVEY.md §8d)",
         "config": {
-            "workload": f"{args.workload}: {w.nv}x{w.nw} (v,w) grid, {w.n_people} pedestrians, "
-                        f"{w.map_size}x{w.map_size} costmap, sim_time={w.sim_time} s, "
-                        f"sim_granularity={w.sim_granularity} ({w.n_steps} steps), 16-gon footprint",
+            "workload": workload_text(w),
             "samples_per_gpu": job.n_local,
-            "parallelism": f"linvel rows sharded over {world} GPU(s), all-reduce(min) of the 4-double selection key"
-                           if world > 1 else "single GPU",
+            "timed_call": ("sfw_grid_launch + selection fetch only (--resident)" if args.resident else
+                           "blocking sfw_grid_stage + sfw_grid_launch + sfw_grid_fetch incl. the 8*T-byte cost vector "
+                           "(= sfw_score_grid); world state resident"),
+            "parallelism": (f"linvel rows sharded over {world} GPU(s): one {w.nv // world}-row block per rank, "
+                            "all-reduce(min) of the [N,4] f64 selection-key table per step") if world > 1 else "single GPU",
         },
         "kernel_ms": {"rollout": res["k1_ms"], "social": res["k2_ms"], "argmin": res["k3_ms"],
                       "launch_total": res["launch_ms"]},
+        "kernel_only_value": job.n_scored * world / (res["launch_ms"] * 1e-3),
         "cmd_vel": {"vx": res["best"]["vx"], "vtheta": res["best"]["vtheta"], "cost": res["best"]["cost"],
                     "index": res["best"]["index"], "n_valid": res["best"]["n_valid"]},
         "roofline": roofline_for(job, res["k2_ms"], args.precision),
@@ -320,67 +409,86 @@ def main():
     if world > 1:
         from social_force_window_planner_amd import multi_gpu
 
-        gvx, gvth, gidx = multi_gpu.cmd_from_key(res["global_key"], len(job.ang), job.scene.linvels, job.ang)
+        gvx, gvth, gidx = multi_gpu.cmd_from_key(res["global_key"], len(job.ang), job.lin_all, job.ang)
         out["global_cmd_vel"] = {"vx": gvx, "vtheta": gvth, "index": gidx,
                                  "cost": res["global_key"][0] if res["global_key"] else -1.0,
                                  "winner_rank": res["winner_rank"]}
-    if rank == 0 and world == 1:
+        out["per_rank"] = res["per_rank"]
+    extra = {}
+    wanted = set() if (args.no_extra or args.resident) else set(args.extras.split(","))
+    if "cfg5_strong" in wanted:
+        # BASELINE.json config 5 sharded over the N ranks (strong scaling); N = 1: the whole
+        # 16.8 M-sample grid on one GPU, in table chunks
+        del job, res
+        r5 = run_config("cfg5", args.precision, 2, 1, ctx, scaling="strong")
+        j5 = r5["job"]
+        extra["cfg5_strong"] = {
+            "workload": workload_text(j5.workload) + f", rows sharded over {world} GPU(s)",
+            "value": r5["n_scored_total"] * 2 / r5["elapsed"], "unit": "trajectories/s", "steps": 2, "warmup": 1,
+            "ms_per_step": r5["elapsed"] / 2 * 1e3, "n_gpus": world, "scaling": "strong",
+            "samples_per_gpu": j5.n_local, "chunks_per_gpu": j5.plan["chunks"],
+            "per_rank": r5["per_rank"] or {"social_kernel_ms": [r5["k2_ms"]], "median_step_ms": [r5["median_step_ms"]],
+                                           "exchange_us": [0.0]},
+            "roofline_frac_rank0": roofline_for(j5, r5["k2_ms"], args.precision, brief=True),
+        }
+        del j5, r5
+    if rank == 0 and world == 1 and not args.resident:
+        job = GridJob(args.workload, args.precision, 0, 1, local_rank)
         if args.verify:
             from oracle.sfw_oracle import OracleScorer
             from social_force_window_planner_amd._abi import default_params
 
             o = OracleScorer(default_params(**job.params_kw))
             o.load_scene(job.scene)
-            costs, _, _ = job.scorer.fetch(want_costs=True)
-            rows = np.unique(np.linspace(0, len(job.lin) - 1, 8).round().astype(int))
+            costs, best, _ = job.step()
+            rows = np.unique(np.linspace(0, len(job.lin) - 1, 4).round().astype(int))
             oc, _ = o.score_grid(job.scene.robot_state, job.lin[rows], job.ang, job.scene.goal_args,
                                  n_threads=os.cpu_count())
             gc = costs.reshape(len(job.lin), len(job.ang))[rows].ravel()
             v = oc >= 0
             out["verify"] = {"max_rel_err": float((np.abs(gc[v] - oc[v]) / np.abs(oc[v])).max()),
                              "same_invalid_set": bool(np.array_equal(oc < 0, gc < 0)), "rows": len(rows)}
-        if not args.no_extra:
-            # PCIe-inclusive form: the blocking sfw_score_grid call (H2D of the sample vectors,
-            # all kernels, D2H of the whole cost vector + selection), world state already uploaded
+        if "upload" in wanted:
             t0 = time.perf_counter()
-            reps = max(3, args.steps // 2)
-            for _ in range(reps):
-                job.scorer.score_grid(job.scene.robot_state, job.lin, job.ang, job.scene.goal_args)
-            dtb = (time.perf_counter() - t0) / reps
-            t0 = time.perf_counter()
+            reps = 5
             for _ in range(reps):
                 job.scorer.load_scene(job.scene)
-            dtw = (time.perf_counter() - t0) / reps
-            out.setdefault("extra", {})["host_buffers"] = {
-                "score_grid_blocking_traj_per_s": job.n_scored / dtb, "score_grid_blocking_ms": dtb * 1e3,
-                "world_upload_ms": dtw * 1e3,
-                "note": "never `value`: includes the 8*T-byte cost-vector D2H; world_upload = costmap+footprint+agents H2D"}
-            job.scorer.stage(job.scene.robot_state, job.lin, job.ang, job.scene.goal_args, job.index_base)
-        if not args.no_extra and args.workload != "target":
-            # the north-star target configuration (50 pedestrians, 40 steps), fewer steps
-            r2 = run_single_config("target", args.precision, max(2, args.steps // 4), 1, ctx)
-            j2 = r2["job"]
-            out.setdefault("extra", {})["target"] = {
-                "workload": f"target: {j2.workload.nv}x{j2.workload.nw} grid, {j2.workload.n_people} pedestrians, "
-                            f"{j2.workload.n_steps} steps",
-                "value": r2["n_scored_total"] * max(2, args.steps // 4) / r2["elapsed"],
-                "unit": "trajectories/s",
-                "kernel_ms": {"rollout": r2["k1_ms"], "social": r2["k2_ms"], "argmin": r2["k3_ms"]},
-                "roofline_frac": roofline_for(j2, r2["k2_ms"], args.precision)["frac"],
-            }
-        if not args.no_extra and args.precision == "f64":
-            # opt-in fast mode (forces in float, state/thresholds in double): same workload
-            r3 = run_single_config(args.workload, "f32", max(2, args.steps // 4), 1, ctx)
-            out.setdefault("extra", {})["f32_forces_mode"] = {
-                "value": r3["n_scored_total"] * max(2, args.steps // 4) / r3["elapsed"], "unit": "trajectories/s",
-                "kernel_ms": {"social": r3["k2_ms"]}, "same_cmd_vel_as_f64": r3["best"]["index"] == res["best"]["index"],
-                "note": "not the headline: costs within 1e-4 (measured <= 3e-5) of the f64 oracle"}
+            job.scorer.sync()
+            extra["world_upload_ms"] = (time.perf_counter() - t0) / reps * 1e3  # costmap + footprint + agents H2D
+        if "resident" in wanted:
+            r_res = run_config(args.workload, args.precision, max(5, args.steps // 2), 2, ctx, resident=True)
+            extra["resident_launch"] = {
+                "value": r_res["n_scored_total"] * r_res["steps"] / r_res["elapsed"], "unit": "trajectories/s",
+                "ms_per_step": r_res["elapsed"] / r_res["steps"] * 1e3,
+                "note": "launch + 48-byte selection fetch only, grid staged once (round-1 headline form)"}
+        for name in ("cfg2", "cfg2_o64", "cfg3", "cfg4"):
+            if name in wanted and name != args.workload:
+                extra[name] = extra_entry(name, args.precision, args.extra_steps, 2, ctx)
+        if "f32" in wanted:
+            if args.precision == "f64":
+                # opt-in fast mode (forces in float, state/thresholds in double): same workload
+                st = max(5, args.steps // 3)
+                r3 = run_config(args.workload, "f32", st, 1, ctx)
+                extra["f32_forces_mode"] = {
+                    "value": r3["n_scored_total"] * st / r3["elapsed"], "unit": "trajectories/s",
+                    "kernel_ms": {"social": r3["k2_ms"]},
+                    "same_cmd_vel_as_f64": r3["best"]["index"] == out["cmd_vel"]["index"],
+                    "note": "not the headline: costs within 1e-4 (measured <= 3e-5) of the f64 oracle"}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(job.scene, job.params_kw)
+            out["cpu_baseline"] = cpu_baseline(_scene_with_grid(job), job.params_kw)
+    if extra:
+        out["extra"] = extra
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _scene_with_grid(job):
+    """The job's scene with the job's sample vectors (GridJob builds the scene on a 2 x 2 grid)."""
+    sc = dataclasses.replace(job.scene)
+    sc.linvels, sc.angvels = job.lin, job.ang
+    return sc
 
 
 if __name__ == "__main__":

@@ -50,6 +50,11 @@ typedef enum sfw_status {
 #define SFW_COST_SKIPPED (-2.0) /* the (0,0) sample the grid loop never scores
                                    (src/sfw_planner.cpp:349-352)             */
 
+/* Robot agent id for callers that have none to give (the reference never sets
+ * agents_[0].id, src/sensor_interface.cpp:31-37): no people_msgs tag parses to
+ * it, so no person's robot-induced social work is skipped by an id collision. */
+#define SFW_ROBOT_ID_NONE INT32_MIN
+
 /* Arithmetic mode of the social-force kernel. */
 #define SFW_PRECISION_F64 0 /* parity mode: everything in double            */
 #define SFW_PRECISION_F32 1 /* fast mode: agent state, integration and every

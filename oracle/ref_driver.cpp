@@ -3,7 +3,7 @@
 // LineIterator and src/trajectory.cpp.  The reference sources are compiled
 // where they lie (-I$(REF)/include, $(REF)/src/trajectory.cpp); nothing is
 // copied into this repo.  Output goes to oracle/_ref/ (git-ignored).
-// Used only by tests/test_oracle_ref.py and tests/golden/make_golden.py to pin
+// Used only by tests/test_oracle_kat.py and tests/golden/make_golden.py to pin
 // the oracle's Bresenham restatement against the real reference code.
 #include <social_force_window_planner/line_iterator.hpp>
 #include <social_force_window_planner/trajectory.hpp>

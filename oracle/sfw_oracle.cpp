@@ -6,7 +6,7 @@
 //
 // PARITY STATUS
 //   * Bresenham cell sequences: pinned against the reference's own
-//     line_iterator.hpp (oracle/_ref, tests/test_oracle_ref.py).
+//     line_iterator.hpp (oracle/_ref, tests/test_oracle_kat.py).
 //   * scoreTrajectory / computeSocialWork / selection rule / footprint cost:
 //     restated from the reference text (citations below); the reference has no
 //     tests or golden vectors and its .cpp files cannot be compiled here
@@ -799,6 +799,7 @@ void *sfwo_si_create(const float *p, double tx, double ty, double yaw, int32_t t
   r.desired_velocity = h->max_robot_vel_x;  // ref :33-37
   r.radius = h->robot_radius;
   r.group_id = -1;
+  r.id = SFW_ROBOT_ID_NONE;  // never set by the reference; a value no tracker tag takes (include/sfw_hip.h)
   h->agents.push_back(r);
   return h;
 }

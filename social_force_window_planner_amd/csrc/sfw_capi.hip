@@ -106,6 +106,9 @@ struct sfw_planner_s {
   std::vector<char> h_agents;       // pos | vel | const | obstacles | grp | off | mem, 16-byte aligned parts
   size_t ao_vel = 0, ao_cst = 0, ao_obs = 0, ao_grp = 0, ao_off = 0, ao_mem = 0;
   int A = 0, O = 0, NG = 0, n_grp_mem = 0;
+  // ordered pairs (i, j) of agents with equal velocities at hand-over (e.g. standing people): see rest_forces
+  std::vector<std::pair<int32_t, int32_t>> rest_pairs;
+  const double *d_agent_rest = nullptr;  // A x (fx, fy) in `world`, or null when there is no such pair
   // what the last stage uploaded (sfw_set_* after a stage take effect at the next stage; a launch
   // in between must keep describing the device copy)
   int st_K = 0, st_A = 0, st_O = 0, st_NG = 0, st_n_grp_mem = 0;
@@ -158,6 +161,15 @@ struct sfw_planner_s {
   sfw_sel *d_sel = nullptr;
   dev_buf<double> points;
   dev_buf<int32_t> n_points;
+  dev_buf<char> one_out;  // sfw_score_one: cost | n_points | coll_step | points, contiguous -> one D2H
+  // scratch outputs of sfw_grid_points_batch's K1 re-run (kept across calls: hipMalloc/hipFree synchronise the device)
+  dev_buf<int32_t> pts_status;
+  dev_buf<double> pts_base, pts_costs;
+  dev_buf<sfw_robot_step> pts_rstep;
+  dev_buf<sfw_pose_frame> pts_frame;
+  dev_buf<int16_t> pts_fcode;
+  // sfw_set_params bumps params_epoch; the table sizes and the shared-prefix plan carry the epoch they were made for
+  uint64_t params_epoch = 1, plan_epoch = 0;
   size_t table_budget_bytes = size_t(2) << 30;  // K1->K2 robot-step table per chunk
   pinned_buf pin_map, pin_world, pin_out, pin_cls;
 };
@@ -220,6 +232,7 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.agent_pos = h->d_agent_pos;
   L.agent_vel = h->d_agent_vel;
   L.agent_c = h->d_agent_c;
+  L.agent_rest = h->d_agent_rest;
   L.A = h->st_A;
   L.obstacles = h->d_obstacles;
   L.O = h->st_O;
@@ -462,6 +475,71 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   return SFW_OK;
 }
 
+// Pairs at exact relative rest (w = v_i - v_j = 0: two standing people, a stopped robot next to a standing
+// person).  There the model's interaction angle theta is mathematically 0 and its angular term
+// -sign(theta) exp(-d/B - (n B theta)^2) leftNormal(Ihat) is discontinuous.  The kernels take sign(theta) from
+// w x diff, exactly 0 here, so their angular term vanishes.  lightsfm instead forms theta as the difference
+// of two atan2 of vectors equal up to rounding (angle(dhat) - angle(I/|I|), I = lambda*0 + dhat), so its
+// sign(theta) is -1, 0 or +1 by the rounding of the HOST's libm — a full-magnitude lateral force on an
+// ordinary scene.  Velocities can only coincide in the state the caller hands over (from step 1 on every
+// agent has been pushed by a different force), and that state is the same for every sample, so this term
+// is evaluated here, once per stage, with the same expression sequence and the same libm the reference would
+// run on this host (computeSocialForce), and added to the agents' starting forces.
+// out: A x (fx, fy).
+void rest_forces(const sfw_planner_s *h, double *out) {
+  const char *base = h->h_agents.data();
+  const double *pos = reinterpret_cast<const double *>(base), *vel = reinterpret_cast<const double *>(base + h->ao_vel);
+  const sfw_params &p = h->params;
+  for (int i = 0; i < 2 * h->A; ++i) out[i] = 0.0;
+  for (const auto &pr : h->rest_pairs) {
+    const int i = pr.first, j = pr.second;
+    const double dx = pos[2 * j] - pos[2 * i], dy = pos[2 * j + 1] - pos[2 * i + 1];  // diff = other - me
+    const double dn = std::sqrt(dx * dx + dy * dy);
+    if (!(dn > 0.0)) continue;
+    const double ux = dx / dn, uy = dy / dn;                                          // diffDirection
+    const double wx = vel[2 * i] - vel[2 * j], wy = vel[2 * i + 1] - vel[2 * j + 1];  // velDiff (= 0)
+    const double ix = p.sfm_lambda * wx + ux, iy = p.sfm_lambda * wy + uy;            // interactionVector
+    const double il = std::sqrt(ix * ix + iy * iy);
+    const double ex = ix / il, ey = iy / il;                                          // interactionDirection
+    double theta = std::atan2(uy, ux) - std::atan2(ey, ex);                           // angleTo, kept in (-pi, pi]
+    while (theta <= -M_PI) theta += 2.0 * M_PI;
+    while (theta > M_PI) theta -= 2.0 * M_PI;
+    if (theta == 0.0) continue;
+    const double B = p.sfm_gamma * il, sq = p.sfm_n * B * theta;
+    const double fa = -(theta > 0.0 ? 1.0 : -1.0) * std::exp(-dn / B - sq * sq);
+    out[2 * i] += p.sfm_force_factor_social * fa * -ey;                               // leftNormal = (-y, x)
+    out[2 * i + 1] += p.sfm_force_factor_social * fa * ex;
+  }
+}
+
+// Everything of a stage that depends on sfw_params: the K1->K2 tables ([S][chunk] records, chunk bounded
+// by the table budget) and the shared-prefix plan (classes of the velocity sequences under dt = sim_time/S).
+// Run by every stage, and again by a launch when sfw_set_params came in between (the reference re-reads
+// its parameters every cycle, :125): a plan made for another dt would merge samples whose robot
+// trajectories now differ.
+int plan_tables(sfw_handle h) {
+  const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
+  const int S = num_steps_of(h->params);
+  int64_t chunk = static_cast<int64_t>(
+      h->table_budget_bytes / ((sizeof(sfw_robot_step) + sizeof(sfw_pose_frame) + sizeof(int16_t)) * S));
+  if (chunk < 1024) chunk = 1024;
+  if (chunk > T) chunk = T;
+  SFW_HIP(h, h->rstep.reserve(static_cast<size_t>(chunk) * S));
+  SFW_HIP(h, h->frame.reserve(static_cast<size_t>(chunk) * S));
+  SFW_HIP(h, h->fcode.reserve(static_cast<size_t>(chunk) * S));
+  if (int e = plan_prefix(h, chunk, S)) return e;
+  h->plan_epoch = h->params_epoch;
+  return SFW_OK;
+}
+
+// The agent / laser-point set must fit one wave's LDS allocation (160 KiB per CU).
+int check_lds(sfw_handle h, int64_t items) {
+  const size_t lds = sfw_social_lds_bytes(h->st_A, h->st_O, h->st_NG, h->st_n_grp_mem, items);
+  if (h->st_A > 0 && lds > 160 * 1024)
+    return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
+  return SFW_OK;
+}
+
 int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int32_t nv, const double *ang,
                  int32_t nw, const sfw_goal_args *args, double vy_samp, int skip_zero, int64_t index_base) {
   if (!h) return SFW_ERR_INVALID_ARG;
@@ -473,9 +551,11 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   h->h_ang.assign(ang, ang + nw);
   {  // one arena, one copy: footprint | agents blob | linvels | angvels
     auto up16 = [](size_t b) { return (b + 15) & ~size_t(15); };
+    const bool rest = !h->rest_pairs.empty();
     const size_t o_fp = 0, o_ag = o_fp + up16(sizeof(double) * (h->h_footprint.empty() ? 2 : h->h_footprint.size())),
                  o_lin = o_ag + up16(h->h_agents.size()), o_ang = o_lin + up16(sizeof(double) * nv),
-                 total = o_ang + up16(sizeof(double) * nw);
+                 o_rest = o_ang + up16(sizeof(double) * nw),
+                 total = o_rest + (rest ? up16(sizeof(double) * 2 * static_cast<size_t>(h->A)) : 0);
     SFW_HIP(h, h->pin_world.reserve(total));
     SFW_HIP(h, h->world.reserve(total));
     char *pb = h->pin_world.p;
@@ -483,6 +563,7 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     if (!h->h_agents.empty()) std::memcpy(pb + o_ag, h->h_agents.data(), h->h_agents.size());
     std::memcpy(pb + o_lin, lin, sizeof(double) * nv);
     std::memcpy(pb + o_ang, ang, sizeof(double) * nw);
+    if (rest) rest_forces(h, reinterpret_cast<double *>(pb + o_rest));
     SFW_HIP(h, hipMemcpyAsync(h->world.p, pb, total, hipMemcpyHostToDevice, h->stream));
     SFW_HIP(h, h->pin_world.mark(h->stream));
     const char *db = h->world.p;
@@ -496,6 +577,7 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     h->d_grp_mem = reinterpret_cast<const int32_t *>(db + o_ag + h->ao_mem);
     h->d_linvels = reinterpret_cast<const double *>(db + o_lin);
     h->d_angvels = reinterpret_cast<const double *>(db + o_ang);
+    h->d_agent_rest = rest ? reinterpret_cast<const double *>(db + o_rest) : nullptr;
   }
   h->st_K = h->K;
   h->st_A = h->A;
@@ -521,16 +603,7 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   SFW_HIP(h, h->costs.reserve(T + (sizeof(sfw_sel) + sizeof(double) - 1) / sizeof(double)));
   h->d_sel = reinterpret_cast<sfw_sel *>(h->costs.p + T);
   SFW_HIP(h, h->partials.reserve(sfw_argmin_partials(T)));
-  // robot-step table: [S][chunk] records, chunk bounded by the table budget
-  const int S = num_steps_of(h->params);
-  int64_t chunk = static_cast<int64_t>(
-      h->table_budget_bytes / ((sizeof(sfw_robot_step) + sizeof(sfw_pose_frame) + sizeof(int16_t)) * S));
-  if (chunk < 1024) chunk = 1024;
-  if (chunk > T) chunk = T;
-  SFW_HIP(h, h->rstep.reserve(static_cast<size_t>(chunk) * S));
-  SFW_HIP(h, h->frame.reserve(static_cast<size_t>(chunk) * S));
-  SFW_HIP(h, h->fcode.reserve(static_cast<size_t>(chunk) * S));
-  if (int e = plan_prefix(h, chunk, S)) return e;
+  if (int e = plan_tables(h)) return e;
   h->staged = true;
   h->launched = false;
   return SFW_OK;
@@ -541,14 +614,14 @@ int launch_common(sfw_handle h) {
   if (!h->staged) return fail(h, SFW_ERR_STATE, "grid_launch before grid_stage");
   SFW_HIP(h, hipSetDevice(h->device));
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
+  // sfw_set_params since the stage: tables and shared-prefix plan are redone for the live parameters
+  if (h->plan_epoch != h->params_epoch)
+    if (int e = plan_tables(h)) return e;
   const int S = num_steps_of(h->params);
-  // the table may have been sized under different params; re-derive the chunk
   int64_t chunk = static_cast<int64_t>(std::min(h->rstep.cap, std::min(h->frame.cap, h->fcode.cap)) / S);
   if (chunk > T) chunk = T;
-  if (chunk < 1) return fail(h, SFW_ERR_STATE, "robot-step table too small (params changed after stage?)");
-  const size_t lds = sfw_social_lds_bytes(h->st_A, h->st_O, h->st_NG, h->st_n_grp_mem, chunk);
-  if (h->st_A > 0 && lds > 160 * 1024)
-    return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
+  if (chunk < 1) return fail(h, SFW_ERR_STATE, "robot-step table too small");
+  if (int e = check_lds(h, chunk)) return e;
   // the shared-prefix plan was laid out for the staged step count and for chunks of whole rows
   const bool prefix = !h->prefix_steps.empty() && h->prefix_S == S && h->prefix_chunk <= chunk;
   if (prefix) chunk = h->prefix_chunk;
@@ -748,6 +821,13 @@ int sfw_destroy(sfw_handle h) {
   h->partials.release();
   h->points.release();
   h->n_points.release();
+  h->one_out.release();
+  h->pts_status.release();
+  h->pts_base.release();
+  h->pts_costs.release();
+  h->pts_rstep.release();
+  h->pts_frame.release();
+  h->pts_fcode.release();
   h->pin_map.release();
   h->pin_world.release();
   h->pin_out.release();
@@ -770,6 +850,7 @@ int sfw_destroy(sfw_handle h) {
 int sfw_set_params(sfw_handle h, const sfw_params *params) {
   if (!h) return SFW_ERR_INVALID_ARG;
   if (int e = check_params(h, params)) return e;
+  if (std::memcmp(&h->params, params, sizeof(sfw_params)) != 0) ++h->params_epoch;
   h->params = *params;
   return SFW_OK;
 }
@@ -865,6 +946,14 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   h->n_grp_mem = n_mem;
   h->A = A;
   h->O = O;
+  h->rest_pairs.clear();
+  for (int i = 0; i < A; ++i)
+    for (int j = i + 1; j < A; ++j)
+      if (agents[i].vx - agents[j].vx == 0.0 && agents[i].vy - agents[j].vy == 0.0 &&
+          !(agents[i].x == agents[j].x && agents[i].y == agents[j].y)) {
+        h->rest_pairs.emplace_back(i, j);
+        h->rest_pairs.emplace_back(j, i);
+      }
   return SFW_OK;
 }
 
@@ -914,26 +1003,34 @@ int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp, doubl
   if (!h) return SFW_ERR_INVALID_ARG;
   if (!cost_out) return fail(h, SFW_ERR_INVALID_ARG, "score_one: cost_out is NULL");
   if (int e = stage_common(h, rs, &vx_samp, 1, &vtheta_samp, 1, args, vy_samp, 0, 0)) return e;
+  if (int e = check_lds(h, 1)) return e;
   const int S = num_steps_of(h->params);
-  SFW_HIP(h, h->points.reserve(static_cast<size_t>(3) * S));
-  SFW_HIP(h, h->n_points.reserve(1));
+  // cost (8) | n_points (4) | coll_step (4) | points (24 S): contiguous on the device, so the latency path
+  // (called on every approach / rotate cycle, ref :204-206, :299-301) pays one pinned D2H, like sfw_grid_fetch
+  const size_t head = 16, pts_bytes = sizeof(double) * 3 * static_cast<size_t>(S);
+  SFW_HIP(h, h->one_out.reserve(head + pts_bytes));
   sfw_launch L;
   fill_launch(h, L, 0, 1, 1);
-  L.points = h->points.p;
-  L.n_points = h->n_points.p;
+  L.costs = reinterpret_cast<double *>(h->one_out.p);
+  L.n_points = reinterpret_cast<int32_t *>(h->one_out.p + 8);
+  L.coll_step = reinterpret_cast<int32_t *>(h->one_out.p + 12);
+  L.points = reinterpret_cast<double *>(h->one_out.p + head);
   SFW_HIP(h, sfw_launch_rollout(L, h->stream));
   SFW_HIP(h, sfw_launch_social(L, h->stream));
-  int32_t n = 0;
-  int32_t coll = -1;
-  SFW_HIP(h, hipMemcpyAsync(cost_out, h->costs.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  SFW_HIP(h, hipMemcpyAsync(&n, h->n_points.p, sizeof(n), hipMemcpyDeviceToHost, h->stream));
-  SFW_HIP(h, hipMemcpyAsync(&coll, h->coll_step.p, sizeof(coll), hipMemcpyDeviceToHost, h->stream));
+  const bool want_pts = points_xyth && points_cap > 0;
+  const size_t fetch = head + (want_pts ? pts_bytes : 0);
+  SFW_HIP(h, h->pin_out.reserve(fetch));
+  SFW_HIP(h, hipMemcpyAsync(h->pin_out.p, h->one_out.p, fetch, hipMemcpyDeviceToHost, h->stream));
   SFW_HIP(h, hipStreamSynchronize(h->stream));
+  int32_t n = 0, coll = -1;
+  std::memcpy(cost_out, h->pin_out.p, sizeof(double));
+  std::memcpy(&n, h->pin_out.p + 8, sizeof(n));
+  std::memcpy(&coll, h->pin_out.p + 12, sizeof(coll));
   if (coll >= 0 && coll + 1 < n) n = coll + 1;  // rejected by contact at step `coll`: poses 0..coll were added
   if (n_points) *n_points = n;
-  if (points_xyth && points_cap > 0 && n > 0) {
+  if (want_pts && n > 0) {
     const int m = n < points_cap ? n : points_cap;
-    SFW_HIP(h, hipMemcpy(points_xyth, h->points.p, sizeof(double) * 3 * m, hipMemcpyDeviceToHost));
+    std::memcpy(points_xyth, h->pin_out.p + head, sizeof(double) * 3 * static_cast<size_t>(m));
   }
   h->staged = false;  // score_one clobbers the staged grid
   h->launched = false;
@@ -1027,28 +1124,25 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
   const size_t n = static_cast<size_t>(count);
   SFW_HIP(h, h->points.reserve(3 * static_cast<size_t>(S) * n));
   SFW_HIP(h, h->n_points.reserve(n));
-  // Re-run K1 for those samples into scratch outputs so the grid results stay intact.
-  dev_buf<int32_t> st;
-  dev_buf<double> bc, cs;
-  dev_buf<sfw_robot_step> tb;
-  dev_buf<sfw_pose_frame> fr;
-  dev_buf<int16_t> fco;
-  hipError_t e = st.reserve(T);
-  if (e == hipSuccess) e = bc.reserve(T);
-  if (e == hipSuccess) e = cs.reserve(T);
-  if (e == hipSuccess) e = tb.reserve(static_cast<size_t>(S) * n);
-  if (e == hipSuccess) e = fr.reserve(static_cast<size_t>(S) * n);
-  if (e == hipSuccess) e = fco.reserve(static_cast<size_t>(S) * n);
+  // Re-run K1 for those samples into scratch outputs so the grid results stay intact.  The scratch is
+  // `count` records long and lives in the handle; the kernels index per-sample outputs by the global
+  // sample index, so the pointers are biased by -first.
+  hipError_t e = h->pts_status.reserve(n);
+  if (e == hipSuccess) e = h->pts_base.reserve(n);
+  if (e == hipSuccess) e = h->pts_costs.reserve(n);
+  if (e == hipSuccess) e = h->pts_rstep.reserve(static_cast<size_t>(S) * n);
+  if (e == hipSuccess) e = h->pts_frame.reserve(static_cast<size_t>(S) * n);
+  if (e == hipSuccess) e = h->pts_fcode.reserve(static_cast<size_t>(S) * n);
   if (e == hipSuccess) {
     sfw_launch L;
     fill_launch(h, L, first, count, count);
-    L.status = st.p;
-    L.base_cost = bc.p;
-    L.costs = cs.p;
+    L.status = h->pts_status.p - first;
+    L.base_cost = h->pts_base.p - first;
+    L.costs = h->pts_costs.p - first;
     L.coll_step = nullptr;  // keep the launch's contact steps
-    L.rstep = tb.p;
-    L.frame = fr.p;
-    L.fcode = fco.p;
+    L.rstep = h->pts_rstep.p;
+    L.frame = h->pts_frame.p;
+    L.fcode = h->pts_fcode.p;
     L.points = h->points.p;
     L.n_points = h->n_points.p;
     e = sfw_launch_rollout(L, h->stream);
@@ -1061,12 +1155,6 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
   if (e == hipSuccess)
     e = hipMemcpyAsync(points_xyth, h->points.p, sizeof(double) * 3 * S * n, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  st.release();
-  bc.release();
-  cs.release();
-  tb.release();
-  fr.release();
-  fco.release();
   if (e != hipSuccess) return hip_fail(h, e, "grid_points");
   // a trajectory rejected by contact at step i holds the poses 0..i (addPoint precedes the test, ref :578, :613-627)
   for (size_t i = 0; i < n; ++i)

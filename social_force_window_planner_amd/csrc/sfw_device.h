@@ -88,6 +88,8 @@ struct sfw_launch {
   const double *agent_pos;         // A x (x,y)
   const double *agent_vel;         // A x (vx,vy)
   const sfw_agent_const *agent_c;  // A
+  const double *agent_rest;        // A x (fx, fy) or null: angular terms of the pairs at exact relative rest in the
+                                   // handed-over state, evaluated on the host (sfw_capi.hip rest_forces)
   int32_t A;
   const double *obstacles;         // O x (x,y)
   int32_t O;

@@ -923,6 +923,10 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
           fy[r] += oy;
         }
       }
+      if (L.agent_rest) {  // pairs at exact relative rest in the handed-over state (robot included)
+        fx[r] += L.agent_rest[2 * i];
+        fy[r] += L.agent_rest[2 * i + 1];
+      }
     }
   }
   __syncthreads();
@@ -1143,6 +1147,10 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
           fx += ox;
           fy += oy;
         }
+      }
+      if (L.agent_rest) {  // pairs at exact relative rest in the handed-over state (robot included)
+        fx += L.agent_rest[2 * sl];
+        fy += L.agent_rest[2 * sl + 1];
       }
       s.frc[sl] = double2{fx, fy};
       s.frj[sl] = double2{0.0, 0.0};

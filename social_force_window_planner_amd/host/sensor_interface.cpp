@@ -15,7 +15,10 @@ SFMSensorInterface::SFMSensorInterface(const InterfaceParams &params, TransformL
   robot.radius = iface_params_.robot_radius_;
   robot.has_goal = 0;
   robot.group_id = -1;
-  robot.id = 0;  // never set by the reference; 0 = value-initialised storage
+  // The reference never sets the robot's id while computeSocialWork's single-agent force
+  // skips a person whose id equals the robot's (ref :692-699): a value no tracker tag can take keeps
+  // every person's Wp term (a person tagged "0" would lose it with id 0).
+  robot.id = SFW_ROBOT_ID_NONE;
   agents_.assign(1, robot);
 }
 

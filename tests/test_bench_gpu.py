@@ -28,7 +28,8 @@ def _port():
 
 
 def test_single_gpu_line():
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--verify"], cwd=ROOT,
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--verify", "--extras",
+                        "upload,resident,cfg2,cfg2_o64", "--extra-steps", "3"], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -36,10 +37,19 @@ def test_single_gpu_line():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None
-    assert d["dtype"] == "f64" and d["higher_is_better"] is True and "cfg2" in d["config"]["workload"]
-    assert d["value"] > 1e6  # north-star floor, on the N=20 configuration
+    assert d["dtype"] == "f64" and d["higher_is_better"] is True
+    # the default workload is the configuration the metric is quoted on: the north-star target
+    assert d["config"]["workload"].startswith("target: 256x256 (v,w) grid, 50 pedestrians")
+    assert "sfw_grid_fetch" in d["config"]["timed_call"]
+    assert d["value"] > 1e6  # the north-star bar, through the blocking call incl. the cost-vector D2H
+    assert d["kernel_only_value"] >= d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "valu" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert 0 < rf["executed_frac"] <= rf["frac"]
+    ex = d["extra"]
+    assert ex["cfg2"]["value"] > 1e6 and 0 < ex["cfg2"]["roofline_executed_frac"] <= ex["cfg2"]["roofline_frac"]
+    assert "64 laser points" in ex["cfg2_o64"]["workload"] and ex["cfg2_o64"]["value"] < ex["cfg2"]["value"]
+    assert ex["resident_launch"]["value"] >= 0.9 * d["value"]
     assert rf["hbm"]["unit"] == "GB/s" and rf["hbm"]["frac"] < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["all_cores"]["cores"] >= 1
@@ -54,9 +64,10 @@ def test_two_ranks_on_one_gpu_over_gloo():
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d2 = _last_json(r.stdout)
-    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["config"]["samples_per_gpu"] == 16384
-    # the same 256x128 grid scored by one process selects the same command
-    r1 = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--grid", "256x128",
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["config"]["samples_per_gpu"] == 65536
+    assert len(d2["per_rank"]["social_kernel_ms"]) == 2 and min(d2["per_rank"]["exchange_us"]) > 0
+    # the same 512x256 grid scored by one process selects the same command
+    r1 = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--grid", "512x256",
                          "--no-cpu-baseline", "--no-extra"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r1.returncode == 0, r1.stderr[-2000:]
     d1 = _last_json(r1.stdout)

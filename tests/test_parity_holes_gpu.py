@@ -1,0 +1,313 @@
+"""Parity cases the round-1 suite avoided or never reached ("what's weak" 1-4):
+
+* pairs at exact relative rest (standing people, a stopped robot): the one input class where the
+  reference's interaction angle is libm rounding noise;
+* real cost ties and the 10000.0 cap through the DEVICE selection (ref src/sfw_planner.cpp:344, :394-414);
+* BASELINE.json config 5 (4096 x 4096, 100 pedestrians) in f64: a sub-grid against the oracle and one
+  rank's 512 x 4096 shard through the size-independent properties;
+* sfw_set_params between sfw_grid_stage and sfw_grid_launch.
+
+All through the C ABI (ctypes), all against oracle/ on the same inputs.
+"""
+import dataclasses
+import math
+
+import numpy as np
+import pytest
+
+from social_force_window_planner_amd import synthetic as syn
+from social_force_window_planner_amd._abi import SFW_PRECISION_F32, default_params
+
+from test_parity_gpu import RTOL_F64, RTOL_NORTH_STAR, _assert_parity, _full_size_properties, _params_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(oracle_mod, hip_mod, scene, params, lin=None, ang=None, rs=None, ga=None, n_threads=8, oracle_params=None):
+    o = oracle_mod.OracleScorer(oracle_params or params)
+    o.load_scene(scene)
+    g = hip_mod.HipScorer(params)
+    g.load_scene(scene)
+    lin = scene.linvels if lin is None else lin
+    ang = scene.angvels if ang is None else ang
+    rs = scene.robot_state if rs is None else rs
+    ga = scene.goal_args if ga is None else ga
+    oc, ob = o.score_grid(rs, lin, ang, ga, n_threads=n_threads)
+    gc, gb = g.score_grid(rs, lin, ang, ga)
+    return oc, ob, gc, gb
+
+
+# ---------------------------------------------------------------------------
+# exact relative rest
+# ---------------------------------------------------------------------------
+def _stand(a):
+    a.vx = a.vy = 0.0
+    a.goal_x, a.goal_y = a.x, a.y  # naive goal = pos + t * vel (ref src/sensor_interface.cpp:494-503)
+
+
+def _rest_scene(n_people, seed, robot_moving, nv=8, nw=9):
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=nv, nw=nw, n_people=n_people, seed=seed)
+    scene = syn.make_scene(w)
+    ag = scene.agents
+    for i in (1, 2, 3):          # three standing people: what a tracker reports for static persons
+        _stand(ag[i])
+    for i in (4, 5):             # a standing pair inside a group, close enough for the group terms
+        _stand(ag[i])
+        ag[i].group_id = 7
+    ag[5].x, ag[5].y = ag[4].x + 0.5, ag[4].y + 0.3
+    ag[5].goal_x, ag[5].goal_y = ag[5].x, ag[5].y
+    # two people walking side by side with bit-identical velocities
+    ag[7].vx, ag[7].vy = ag[6].vx, ag[6].vy
+    ag[7].goal_x, ag[7].goal_y = ag[7].x + 2.0 * ag[7].vx, ag[7].y + 2.0 * ag[7].vy
+    rs = scene.robot_state
+    if not robot_moving:         # a stopped robot: its agent velocity (local twist) is (0, 0) too
+        rs = (rs[0], rs[1], rs[2], 0.0, 0.0, 0.0)
+        ag[0].vx = ag[0].vy = 0.0
+    return scene, rs
+
+
+@pytest.mark.parametrize("robot_moving", [True, False])
+@pytest.mark.parametrize("n_people,seed", [(12, 501), (30, 502), (70, 503)])
+def test_pairs_at_exact_relative_rest(oracle_mod, hip_mod, n_people, seed, robot_moving):
+    """Standing people (v = 0,0), a standing pair inside a group, two walkers with bit-identical velocities
+    and (second variant) a stopped robot.  lightsfm's sign(theta) for such a pair is the rounding of two atan2
+    (oracle: sfm_pair); the library evaluates exactly those terms on the host with the host's libm
+    (sfw_capi.hip rest_forces), the kernels do the rest: identical sentinel sets, identical selection, costs
+    within the f64 tolerance — and the scene really contains such pairs whose noise sign is not 0."""
+    scene, rs = _rest_scene(n_people, seed, robot_moving)
+    # the angular term at rest is not identically zero on this scene: the oracle's own costs move when the
+    # rest is broken by 1e-9 m/s (far below anything else in the scene)
+    p = default_params()
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, p, rs=rs)
+    assert (oc >= 0).sum() > 10
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+    pert = syn.make_scene(scene.workload)
+    for i in range(len(scene.agents)):
+        for f in ("x", "y", "vx", "vy", "goal_x", "goal_y", "group_id", "has_goal", "goal_radius"):
+            setattr(pert.agents[i], f, getattr(scene.agents[i], f))
+    for i in (1, 2, 3, 4, 5, 7):
+        pert.agents[i].vx += 1e-9 * i
+    o = oracle_mod.OracleScorer(p)
+    o.load_scene(pert)
+    oc2, _ = o.score_grid(rs, scene.linvels, scene.angvels, scene.goal_args, n_threads=8)
+    v = (oc >= 0) & (oc2 >= 0)
+    moved = np.max(np.abs(oc2[v] - oc[v]) / np.abs(oc[v]))
+    assert moved > 1e-6, f"scene does not exercise the discontinuity (oracle moved by {moved:.1e})"
+    # f32-forces mode: same host-evaluated terms, north-star tolerance
+    pf = default_params(precision=SFW_PRECISION_F32)
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, pf, rs=rs, oracle_params=p)
+    assert np.array_equal(oc < 0, gc < 0)
+    v = oc >= 0
+    assert np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= RTOL_NORTH_STAR
+
+
+def test_relative_rest_on_a_gpu_filling_grid(oracle_mod, hip_mod):
+    """The same through the shared-prefix tree and the register-resident organisation (64 x 64 samples)."""
+    scene, rs = _rest_scene(20, 504, True, nv=64, nw=64)
+    p = default_params()
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    gc, gb = g.score_grid(rs, scene.linvels, scene.angvels, scene.goal_args)
+    assert g.plan_info()["levels"] > 0
+    o = oracle_mod.OracleScorer(p)
+    o.load_scene(scene)
+    rows = [0, 21, 63]
+    oc, _ = o.score_grid(rs, scene.linvels[rows], scene.angvels, scene.goal_args, n_threads=8)
+    sub = gc.reshape(64, 64)[rows].ravel()
+    assert np.array_equal(oc < 0, sub < 0)
+    v = oc >= 0
+    assert np.max(np.abs(sub[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64
+
+
+# ---------------------------------------------------------------------------
+# real ties and the 10000.0 cap through the device argmin (K3)
+# ---------------------------------------------------------------------------
+def _tie_scene(nv, nw, sampler):
+    """theta = 0, way-point on the x axis, no people, empty map, point footprint: the +w and -w samples of a
+    linvel row are mirror images, their costs bit-equal."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg1"], nv=nv, nw=nw, sampler=sampler, footprint="point", map_size=400)
+    scene = syn.make_scene(w)
+    assert not scene.cells.any()
+    return scene, (1.0, 0.0, 1.0, 2.0, 0.0)  # acc_x, acc_y, acc_theta, wpx, wpy = (2, 0)
+
+
+def _sequential_selection(lin, ang, costs):
+    """The reference's scan, literally (ref :338-344, :394-414): returns the winning flat index or -1."""
+    best_cost, best_xv, best_thv, best_i, traj_cost = 10000.0, 0.0, 0.0, -1, -1.0
+    nw = len(ang)
+    for iv, lv in enumerate(lin):
+        for iw, av in enumerate(ang):
+            c = costs[iv * nw + iw]
+            if lv == 0.0 and av == 0.0:
+                continue
+            if c >= 0 and c <= best_cost:
+                if c == best_cost:
+                    if lv < best_xv:
+                        continue
+                    if lv == best_xv and abs(av) > abs(best_thv):
+                        continue
+                best_cost, best_xv, best_thv, best_i, traj_cost = c, lv, av, iv * nw + iw, c
+    return best_i if traj_cost != -1.0 else -1
+
+
+@pytest.mark.parametrize("nv,nw,sampler", [(5, 9, "reference"), (128, 128, "generalised"), (33, 65, "generalised")])
+def test_mirror_ties_through_the_device_selection(oracle_mod, hip_mod, nv, nw, sampler):
+    scene, ga = _tie_scene(nv, nw, sampler)
+    ang = scene.angvels
+    # (1) velocity + squared-distance terms only: the +w / -w samples of a row tie bit-for-bit (dy -> -dy).  With
+    #     the angle term they need not: the reference's float normalizeAngle (sfw_planner.hpp:399-407) rounds
+    #     val + pi differently for +val and -val.
+    p = default_params(sim_time=0.5, angle_weight=0.0)
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, p, ga=ga)
+    grid, ogrid = gc.reshape(nv, nw), oc.reshape(nv, nw)
+    n_tied = 0
+    for iw in range(nw):
+        for jw in range(iw + 1, nw):
+            if ang[iw] == -ang[jw] and ang[iw] != 0.0:
+                assert np.array_equal(grid[:, iw], grid[:, jw]), "mirror samples must tie exactly (device)"
+                assert np.array_equal(ogrid[:, iw], ogrid[:, jw]), "mirror samples must tie exactly (oracle)"
+                n_tied += 1
+    assert n_tied == nw // 2
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+    sel = _sequential_selection(scene.linvels, ang, gc)
+    assert gb["index"] == sel
+    # among +w / -w with equal cost the later iterate (-w follows +w in the sampler) wins (ref :394-414)
+    iw = sel % nw
+    if ang[iw] != 0.0:
+        assert ang[iw] < 0.0 and gc[sel] == gc[sel - 1] and ang[iw - 1] == -ang[iw]
+    # (2) default weights: whatever ties the float angle term leaves, device selection = sequential scan = oracle
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, default_params(sim_time=0.5), ga=ga)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+    assert gb["index"] == _sequential_selection(scene.linvels, ang, gc)
+
+
+@pytest.mark.parametrize("kind", ["all_equal_1e4", "some_above", "flat_rows"])
+def test_cost_cap_and_flat_ties(oracle_mod, hip_mod, kind):
+    """Costs == 10000.0 (selectable only under the reference's tie rules against the initial best_traj) and
+    > 10000.0 (never selectable) via the weights: with only the velocity term, cost = w_v |max_vel_x - v_end| /
+    max_vel_x depends on the row alone, so whole rows tie."""
+    scene, ga = _tie_scene(9, 9, "generalised")
+    if kind == "all_equal_1e4":
+        # vel_diff == 1 exactly for linvel 0 (v stays 0 with zero start speed) -> cost == 10000.0 there
+        p = default_params(sim_time=0.5, vel_weight=10000.0, distance_weight=0.0, angle_weight=0.0)
+        rs = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    elif kind == "some_above":
+        p = default_params(sim_time=0.5, vel_weight=20000.0, distance_weight=0.0, angle_weight=0.0)
+        rs = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    else:
+        p = default_params(sim_time=0.5, vel_weight=1.0, distance_weight=0.0, angle_weight=0.0)
+        rs = scene.robot_state
+    scene.agents[0].vx = rs[3]
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, p, rs=rs, ga=ga)
+    assert np.array_equal(oc, gc)  # no pedestrians, no map: the two sides run the same IEEE sequence
+    if kind == "all_equal_1e4":
+        assert (gc == 10000.0).any()
+    if kind == "some_above":
+        assert (gc > 10000.0).any() and ((gc >= 0) & (gc < 10000.0)).any()
+    sel = _sequential_selection(scene.linvels, scene.angvels, gc)
+    assert ob["index"] == sel and gb["index"] == sel
+    assert gb["vx"] == ob["vx"] and gb["vtheta"] == ob["vtheta"] and gb["n_valid"] == ob["n_valid"]
+
+
+def test_every_cost_above_the_cap(oracle_mod, hip_mod):
+    """All samples valid, none selectable (cost > 10000.0): zero command, index -1, n_valid = T - 1."""
+    scene, ga = _tie_scene(5, 9, "reference")
+    p = default_params(sim_time=0.5, distance_weight=1e6)
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, p, ga=ga)
+    assert (gc[1:] > 10000.0).all()
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+    assert gb["index"] == -1 and gb["vx"] == 0.0 and gb["vtheta"] == 0.0 and gb["n_valid"] == 44
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json config 5 in f64
+# ---------------------------------------------------------------------------
+def test_cfg5_subgrid_f64(oracle_mod, hip_mod):
+    """cfg5 workload (100 pedestrians, 500 x 500 map, 40 steps), 12 x 12 samples, against the oracle at 1e-9."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg5"], nv=12, nw=12)
+    scene = syn.make_scene(w)
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, _params_for(w), n_threads=64)
+    assert (oc >= 0).sum() > 20
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+def test_cfg5_one_rank_shard_full_size(oracle_mod, hip_mod):
+    """One rank's share of cfg5 on 8 GPUs: linvel rows [512, 1024) of the 4096 x 4096 grid = 2 097 152 samples,
+    through the size-independent properties (determinism, sample independence, device argmin = sequential
+    selection), plus two rows against the oracle."""
+    from social_force_window_planner_amd import multi_gpu
+
+    full = syn.WORKLOADS["cfg5"]
+    lin_all, ang = syn.generalised_sampler(full.nv, full.nw)
+    lo, hi = multi_gpu.shard_rows(full.nv, 1, 8)
+    assert (lo, hi) == (512, 1024)
+    scene = syn.make_scene(dataclasses.replace(full, nv=8, nw=8))  # scene content does not depend on the grid
+    p = _params_for(full)
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    lin = lin_all[lo:hi]
+    g.stage(scene.robot_state, lin, ang, scene.goal_args, index_base=lo * full.nw)
+    g.launch()
+    costs, best, key = g.fetch()
+    g.launch()
+    costs2, best2, key2 = g.fetch()
+    assert np.array_equal(costs, costs2) and best == best2 and key == key2
+    grid = costs.reshape(len(lin), len(ang))
+    rows = np.array([0, 255, 511])
+    sub, _ = g.score_grid(scene.robot_state, lin[rows], ang, scene.goal_args)
+    assert np.array_equal(sub.reshape(3, -1), grid[rows])
+    from test_parity_gpu import _numpy_selection
+
+    sel = _numpy_selection(lin, ang, costs)
+    assert best["index"] == sel and best["n_valid"] == int((costs >= 0).sum())
+    assert key[3] == -float(lo * full.nw + sel)
+    assert np.all(np.isfinite(costs)) and np.all((costs >= 0) | (costs == -1.0) | (costs == -2.0))
+    o = oracle_mod.OracleScorer(p)
+    o.load_scene(scene)
+    cols = np.arange(0, full.nw, 64)  # 64 samples of each of two rows
+    for r in (0, 511):
+        oc, _ = o.score_grid(scene.robot_state, lin[r:r + 1], ang[cols], scene.goal_args, n_threads=64)
+        gsub = grid[r, cols]
+        assert np.array_equal(oc < 0, gsub < 0)
+        v = oc >= 0
+        assert np.max(np.abs(gsub[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64
+
+
+# ---------------------------------------------------------------------------
+# sfw_set_params between stage and launch
+# ---------------------------------------------------------------------------
+def test_set_params_between_stage_and_launch(oracle_mod, hip_mod):
+    """Same step count, different dt (sim_time and sim_granularity both doubled) set AFTER the stage: the
+    shared-prefix classes were derived for the old dt and must not be reused."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=72, nw=72, n_people=9, seed=61)
+    scene = syn.make_scene(w)
+    p1 = default_params(sim_time=1.0, sim_granularity=0.025)
+    p2 = default_params(sim_time=2.0, sim_granularity=0.05)
+    g = hip_mod.HipScorer(p1)
+    g.load_scene(scene)
+    g.stage(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert g.plan_info()["levels"] > 0
+    g.set_params(p2)
+    g.launch()
+    costs, best, _ = g.fetch()
+    fresh = hip_mod.HipScorer(p2)
+    fresh.load_scene(scene)
+    c2, b2 = fresh.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert np.array_equal(costs, c2) and best == b2
+    o = oracle_mod.OracleScorer(p2)
+    o.load_scene(scene)
+    rows = [0, 40, 71]
+    oc, _ = o.score_grid(scene.robot_state, scene.linvels[rows], scene.angvels, scene.goal_args, n_threads=8)
+    sub = costs.reshape(72, 72)[rows].ravel()
+    assert np.array_equal(oc < 0, sub < 0)
+    v = oc >= 0
+    assert np.max(np.abs(sub[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64
+    # a different step count after the stage works too (tables are re-sized)
+    p3 = default_params(sim_time=1.5, sim_granularity=0.025)
+    g.set_params(p3)
+    g.launch()
+    c3, b3, _ = g.fetch()
+    fresh3 = hip_mod.HipScorer(p3)
+    fresh3.load_scene(scene)
+    c3f, b3f = fresh3.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert np.array_equal(c3, c3f) and b3 == b3f
