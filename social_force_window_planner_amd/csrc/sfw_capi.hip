@@ -117,7 +117,7 @@ struct sfw_planner_s {
   const sfw_agent_const *d_agent_c = nullptr;
   const int32_t *d_agent_grp = nullptr, *d_grp_off = nullptr, *d_grp_mem = nullptr;
   const double *d_linvels = nullptr, *d_angvels = nullptr;
-  dev_buf<uint32_t> pair_tab;  // rebuilt when the agent count changes
+  dev_buf<uint16_t> pair_tab;  // rebuilt when the agent count changes
   int pair_tab_A = -1;
 
   // staged grid
@@ -202,6 +202,8 @@ int check_params(sfw_handle h, const sfw_params *p) {
     return fail(h, SFW_ERR_INVALID_ARG, "unknown precision");
   if (!(p->sfm_gamma > 0) || !(p->sfm_relaxation_time > 0) || !(p->sfm_force_sigma_obstacle > 0))
     return fail(h, SFW_ERR_INVALID_ARG, "sfm gamma/relaxation_time/sigma must be > 0");
+  if (!(p->sfm_force_factor_social >= 0))
+    return fail(h, SFW_ERR_INVALID_ARG, "sfm_force_factor_social must be >= 0");
   return SFW_OK;
 }
 

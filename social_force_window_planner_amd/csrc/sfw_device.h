@@ -36,7 +36,7 @@ struct __attribute__((aligned(16))) sfw_agent_const {
 // derived on the device (a division, a product) is a VALU result and would sit in a VGPR pair
 // of every lane for the whole rollout.
 template <typename R> struct sfw_force_k {
-  R lambda, gamma2, neg_inv_gamma, neg_n2, neg_n_prime2, f_social, f_obstacle, inv_sigma;
+  R lambda, neg_inv_gamma, ln_f_social, c_vel, c_ang, f_obstacle, inv_sigma;  // c_vel = -(n' gamma)^2, c_ang = -(n gamma)^2
 };
 struct sfw_derived {
   sfw_force_k<double> d;
@@ -116,8 +116,9 @@ struct sfw_launch {
   const int32_t *in_dead;         // [source classes] 0, or 2 + step of a pedestrian contact so far
   sfw_cls_agent *out_state;       // PREFIX [n_cls][A]
   int32_t *out_dead;              // PREFIX [n_cls]
-  // flat social kernel: pair u -> packed LDS byte offsets (16*i | 16*j << 16), see sfw_launch_pair_table
-  const uint32_t *pair_tab;
+  // flat social kernel: pair u -> LDS plane byte offsets 8*i (first array) and 8*j (second array), padded with the
+  // dummy slot 8*A; see sfw_launch_pair_table
+  const uint16_t *pair_tab;
   // per-sample outputs, indexed by GLOBAL sample index
   int32_t *status;       // T
   double *base_cost;     // T : vel + distance + angle + costmap terms (ref :663-666)
@@ -158,9 +159,9 @@ int64_t sfw_argmin_partials(int64_t T);
 hipError_t sfw_launch_argmin(const double *costs, const double *linvels, const double *angvels,
                              int32_t nw, int64_t T, int64_t index_base, sfw_sel *partials,
                              sfw_sel *out, hipStream_t stream);
-// Pair table of the flat social kernel for A agents: sfw_pair_table_entries(A) dwords.
+// Pair table of the flat social kernel for A agents: sfw_pair_table_entries(A) uint16 entries.
 int64_t sfw_pair_table_entries(int A);
-hipError_t sfw_launch_pair_table(uint32_t *tab, int A, hipStream_t stream);
+hipError_t sfw_launch_pair_table(uint16_t *tab, int A, hipStream_t stream);
 // Samples handled by one wave of the social kernel for A agents.
 int sfw_samples_per_wave(int A, int64_t T);
 size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T);

@@ -33,6 +33,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <cmath>
 
 namespace {
 
@@ -390,9 +391,6 @@ __global__ void __launch_bounds__(64) sfw_rollout_small_kernel(const sfw_launch 
 // threshold (contact, goal pop, speed clamp) are always double.  The template
 // type R is the type the FORCES are evaluated in: double (parity mode) or float
 // (fast mode: differences are formed in double, then rounded to float).
-template <typename R> struct vec2;
-template <> struct vec2<double> { using type = double2; };
-template <> struct vec2<float> { using type = float2; };
 template <typename R> struct tiny_of;
 template <> struct tiny_of<double> { static constexpr double v = 1e-300; };
 template <> struct tiny_of<float> { static constexpr float v = 1e-30f; };
@@ -409,14 +407,49 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned n) {
   return x * q + (x < r ? x : r) + k;
 }
 
-// Per-launch social-force constants in the force type (host-derived, see sfw_derived).
+// The kernel arguments again, through the kernarg segment pointer made opaque at the point of use: a field read
+// through late_args() is loaded (s_load, scalar cache) where it is consumed instead of at kernel entry.  The pair
+// loop needs ~60 SGPRs for its polynomial coefficients and math constants; with every sfw_launch field the
+// per-agent pass and the epilogue use ALSO held in SGPRs across it, the allocator spills coefficients to VGPR lanes
+// and reloads them with v_readlane inside the loop (14 VALU issues per pair in the first version of this layout).
+typedef const __attribute__((address_space(4))) sfw_launch *late_launch;
+__device__ __forceinline__ late_launch late_args() {
+#ifdef SFW_DBG_NO_LAUNDER
+  return (late_launch)__builtin_amdgcn_kernarg_segment_ptr();
+#endif
+  const __attribute__((address_space(4))) void *p =
+      (const __attribute__((address_space(4))) void *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return static_cast<late_launch>(p);  // sfw_launch is the first kernel argument: offset 0 of the segment
+}
+
+// Social-force constants of the PAIR term in the force type (host-derived, see sfw_derived).
 template <typename R> struct sfm_consts {
   sfwm::poly_consts pc;
-  R lambda, gamma2, neg_inv_gamma, neg_n2, neg_n_prime2, f_social;
-  R f_obstacle, inv_sigma;
-  double f_desired, inv_tau, dt, rr;
-  double f_gaze, f_coherence, f_repulsion;
+  R lambda, neg_inv_gamma, ln_f_social, c_vel, c_ang;
 };
+// Constants of the per-agent pass (desired / obstacle / group forces, integration, contact test): read late.
+struct agent_consts {
+  double f_desired, inv_tau, dt, rr, inv_O, f_obstacle, inv_sigma;
+  double f_gaze, f_coherence, f_repulsion;
+  int O, robot_id;
+};
+__device__ __forceinline__ agent_consts load_agent_consts(late_launch La, bool f32) {
+  agent_consts c;
+  c.f_desired = La->k.f_desired;
+  c.inv_tau = La->k.inv_tau;
+  c.dt = La->dt;
+  c.rr = La->k.rr;
+  c.inv_O = La->k.inv_O;
+  c.f_obstacle = f32 ? static_cast<double>(La->k.f.f_obstacle) : La->k.d.f_obstacle;
+  c.inv_sigma = f32 ? static_cast<double>(La->k.f.inv_sigma) : La->k.d.inv_sigma;
+  c.f_gaze = La->p.sfm_force_factor_group_gaze;
+  c.f_coherence = La->p.sfm_force_factor_group_coherence;
+  c.f_repulsion = La->p.sfm_force_factor_group_repulsion;
+  c.O = La->O;
+  c.robot_id = La->agent_c[0].id;
+  return c;
+}
 
 // Force exerted ON agent i BY agent j (one term of lightsfm's
 // computeSocialForce), from diff = pj - pi and
@@ -441,26 +474,28 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   using namespace sfwm;
   const R tiny = tiny_of<R>::v;
   R rd, dn, rl, il;
-  const R d2 = fmax(fma(dx, dx, dy * dy), tiny);  // coincident agents: dhat -> 0, no NaN
+  // + tiny instead of a clamp: far below an ulp of any d2 that matters, and coincident agents (d2 = 0) still
+  // get dhat -> 0 instead of a NaN
+  const R d2 = fma(dx, dx, fma(dy, dy, tiny));
   rsqrt_sqrt(d2, rd, dn);
   const R ux = dx * rd, uy = dy * rd;
   const R ix = fma(k.lambda, wx, ux), iy = fma(k.lambda, wy, uy);
-  const R l2 = fmax(fma(ix, ix, iy * iy), tiny);
+  const R l2 = fma(ix, ix, fma(iy, iy, tiny));
   rsqrt_sqrt(l2, rl, il);
   const R sn = fma(ix, uy, -(iy * ux));  // |I| sin(theta)
   const R cs = fma(ix, ux, iy * uy);     // |I| cos(theta)
   const R theta = atan2_abs(k.pc, fabs(sn), cs, il);  // |(sn,cs)| = |I| since dhat is unit
-  // -|diff| / B, clamped so that exp_fast's integer exponent stays in range for any input
-  // (exp(-800) is 0 in double and in float; the clamp never changes a result)
-  const R a = fmax(dn * rl * k.neg_inv_gamma, R(-800));
-  const R bt2 = (k.gamma2 * l2) * (theta * theta);  // (B theta)^2, B^2 = gamma^2 |I|^2
-  const R ev = exp_fast(k.pc, fma(k.neg_n_prime2, bt2, a));
-  R ea = exp_fast(k.pc, fma(k.neg_n2, bt2, a));
+  // ln Fs - |diff| / B: the force factor rides in the exponent (Fs exp(x) = exp(x + ln Fs)), clamped so that
+  // exp_fast's integer exponent stays in range for any input (exp(-800) is 0 in double and in float; the clamp
+  // never changes a result)
+  const R a = fmax(fma(dn * rl, k.neg_inv_gamma, k.ln_f_social), R(-800));
+  const R t2 = l2 * (theta * theta);      // (B theta)^2 = gamma^2 |I|^2 theta^2; gamma^2 sits in c_vel / c_ang
+  const R ev = exp_fast(k.pc, fma(k.c_vel, t2, a));   // Fs exp(-|diff|/B - (n' B theta)^2)
+  R ea = exp_fast(k.pc, fma(k.c_ang, t2, a));         // Fs exp(-|diff|/B - (n  B theta)^2)
   // sign(theta) * exp(...): sign bit copied from cw, exact zero kept (relative rest)
   ea = (cw != 0.0) ? copysign_from(ea, cw) : R(0);
-  const R sc = rl * k.f_social;
-  const R gx = ix * sc, gy = iy * sc;    // Fs * Ihat
-  // f = -ev * (Fs Ihat) - ea * leftNormal(Fs Ihat),  leftNormal(x,y) = (-y, x)
+  const R gx = ix * rl, gy = iy * rl;    // Ihat
+  // f = -ev * Ihat - ea * leftNormal(Ihat),  leftNormal(x,y) = (-y, x)
   fx = fma(ea, gy, -(ev * gx));
   fy = fma(-ev, gy, -(ea * gx));
 }
@@ -473,15 +508,16 @@ __device__ __forceinline__ void pair_force_state(const sfm_consts<R> &k, double 
   pair_force<R>(k, R(dx), R(dy), R(wx), R(wy), cw, fx, fy);
 }
 
+// |(x, y)|, exactly 0 for the zero vector (the clamp only keeps the reciprocal root finite)
 __device__ __forceinline__ double fast_norm(double x, double y) {
+  const double q = fma(x, x, y * y);
   double rs, sq;
-  sfwm::rsqrt_sqrt(fmax(fma(x, x, y * y), 1e-300), rs, sq);
-  return sq;
+  sfwm::rsqrt_sqrt(fmax(q, 1e-300), rs, sq);
+  return q * rs;
 }
 
 // desiredForce of one person (lightsfm computeDesiredForce), double.
-template <typename R>
-__device__ __forceinline__ void desired_force(const sfm_consts<R> &k, double px, double py, double vx, double vy,
+__device__ __forceinline__ void desired_force(const agent_consts &k, double px, double py, double vx, double vy,
                                               bool has_goal, double gx, double gy, double gr, double dv, double &fx,
                                               double &fy) {
   const double ex = gx - px, ey = gy - py;
@@ -500,32 +536,38 @@ __device__ __forceinline__ void desired_force(const sfm_consts<R> &k, double px,
 // computeObstacleForce).  obs lives in LDS; every lane reads the same address
 // (broadcast).
 template <typename R>
-__device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const double2 *obs, int O, double inv_O,
+__device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const agent_consts &c, const double2 *obs,
                                                double px, double py, double radius, double &fx, double &fy) {
   using namespace sfwm;
   R ax = R(0), ay = R(0);
-  for (int o = 0; o < O; ++o) {
+  const R f_obstacle = static_cast<R>(c.f_obstacle), inv_sigma = static_cast<R>(c.inv_sigma);
+  for (int o = 0; o < c.O; ++o) {
     const double2 q = obs[o];
     const R mx = R(px - q.x), my = R(py - q.y);
     R rm, mn;
     rsqrt_sqrt(fmax(fma(mx, mx, my * my), tiny_of<R>::v), rm, mn);
-    const R e = k.f_obstacle * exp_fast(k.pc, (R(radius) - mn) * k.inv_sigma);  // exp(-(|md| - radius)/sigma)
+    const R e = f_obstacle * exp_fast(k.pc, (R(radius) - mn) * inv_sigma);  // exp(-(|md| - radius)/sigma)
     ax = fma(e * rm, mx, ax);
     ay = fma(e * rm, my, ay);
   }
-  fx = static_cast<double>(ax) * inv_O;
-  fy = static_cast<double>(ay) * inv_O;
+  fx = static_cast<double>(ax) * c.inv_O;
+  fy = static_cast<double>(ay) * c.inv_O;
 }
 
-// LDS map of one wave.  The four state arrays (pos, vel and the two force accumulators) come
-// first (pos, vel, frj, frc) and are `cap` records apart, so with a compile-time cap their distances fold into the
-// DS instructions' offset fields: one address VGPR per agent reaches all four.  The per-agent
-// launch constants are staged only when `consts` is set (the flat kernel without groups reads
-// them from global memory instead: 40 B/agent less LDS, which is what bounds its occupancy for
-// large crowds).  Built on the host with base = nullptr to size the allocation.
+// LDS map of one wave.  Agent state lives in PLANES of `cap` doubles each — px, py, vx, vy, the force
+// accumulators fjx, fjy (received "as j") and, in the flat kernel, fcx, fcy (received "as i") — `cap` doubles
+// apart, so (1) a wave's ds_read_b64 / ds_add_f64 of consecutive agents hit consecutive 8-byte words (all 32
+// banks; with 16-byte (x, y) records every 8-byte access used half the banks twice: 30 % of the LDS-active cycles
+// were bank conflicts, profiles/r02a) and (2) with a compile-time cap the plane distances fold into the DS
+// instructions' offset fields: one address VGPR per agent reaches all eight.  The per-agent launch constants are
+// staged only when `consts` is set (the flat kernel without groups reads them from global memory instead: 40 B/agent
+// less LDS, which is what bounds its occupancy for large crowds).  Built on the host with base = nullptr to size
+// the allocation.
 struct lds_layout {
-  double2 *pos, *vel, *frc, *frj, *goal, *obs, *gcen;
-  sfw_robot_step *rsb;  // this step's robot record of each of the wave's samples (register form)
+  double *px, *py, *vx, *vy, *fjx, *fjy, *fcx, *fcy;
+  double2 *goal, *obs, *gcen;
+  sfw_robot_step *rsb;  // robot records: one per sample of the wave (register form), two (flat form: this step's
+                        // and the prefetched next step's)
   double *gr, *dv, *rad, *swp;
   int *id, *hasgoal, *dead, *grp, *goff, *gmem;
   size_t bytes;
@@ -537,12 +579,17 @@ struct lds_layout {
       base += (n + 15) & ~size_t(15);
       return p;
     };
-    pos = reinterpret_cast<double2 *>(take(sizeof(double2) * cap));
-    vel = reinterpret_cast<double2 *>(take(sizeof(double2) * cap));
-    frj = reinterpret_cast<double2 *>(take(sizeof(double2) * cap));
-    frc = reinterpret_cast<double2 *>(take(sizeof(double2) * (with_frc ? cap : 0)));  // flat kernel only
+    const size_t plane = sizeof(double) * static_cast<size_t>(cap);  // cap is even: planes stay 16-byte aligned
+    px = reinterpret_cast<double *>(take(plane));
+    py = reinterpret_cast<double *>(take(plane));
+    vx = reinterpret_cast<double *>(take(plane));
+    vy = reinterpret_cast<double *>(take(plane));
+    fjx = reinterpret_cast<double *>(take(plane));
+    fjy = reinterpret_cast<double *>(take(plane));
+    fcx = reinterpret_cast<double *>(take(with_frc ? plane : 0));  // flat kernel only
+    fcy = reinterpret_cast<double *>(take(with_frc ? plane : 0));
     obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? O : 1)));
-    rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * G));
+    rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * (with_frc ? 2 : G)));
     swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
     hasgoal = reinterpret_cast<int *>(take(sizeof(int) * GA));
     dead = reinterpret_cast<int *>(take(sizeof(int) * G));
@@ -569,8 +616,8 @@ __device__ __forceinline__ agent_k agent_k_lds(const lds_layout &s, int i) {
   const double2 g = s.goal[i];
   return agent_k{g.x, g.y, s.gr[i], s.dv[i], s.rad[i], s.id[i]};
 }
-__device__ __forceinline__ agent_k agent_k_global(const sfw_launch &L, int i) {
-  const sfw_agent_const c = L.agent_c[i];
+__device__ __forceinline__ agent_k agent_k_global(const sfw_agent_const *agent_c, int i) {
+  const sfw_agent_const c = agent_c[i];
   return agent_k{c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity, c.radius, c.id};
 }
 
@@ -583,8 +630,8 @@ __device__ __forceinline__ agent_k agent_k_global(const sfw_launch &L, int i) {
 //   * (tanh(x) + 1) / 2 = 1 / (1 + exp(-2x));
 //   * |d| < ra + rb is tested as |d|^2 < (ra + rb)^2.
 template <typename R>
-__device__ double2 group_force(const sfm_consts<R> &k, const lds_layout &s, int NG, int g, int A, int i, int sl,
-                               double px, double py) {
+__device__ double2 group_force(const sfm_consts<R> &k, const agent_consts &c, const lds_layout &s, int NG, int g, int A,
+                               int i, int sl, double px, double py) {
   const int q = s.grp[i];
   if (q < 0) return double2{0.0, 0.0};
   const int m0 = s.goff[q], m1 = s.goff[q + 1];
@@ -605,7 +652,7 @@ __device__ double2 group_force(const sfm_consts<R> &k, const lds_layout &s, int 
     const double rx = fma(w, fma(n, cx, -px), -px), ry = fma(w, fma(n, cy, -py), -py);
     const double ep = fma(ddx, rx, ddy * ry);
     if (ep < 0.0) {  // has_dir is implied: ep == 0 without a direction
-      const double sc = k.f_gaze * ep;  // (ep / |dir|^2) dir with |dir| = 1
+      const double sc = c.f_gaze * ep;  // (ep / |dir|^2) dir with |dir| = 1
       fx = sc * ddx;
       fy = sc * ddy;
     }
@@ -614,7 +661,7 @@ __device__ double2 group_force(const sfm_consts<R> &k, const lds_layout &s, int 
     const double rx = cx - px, ry = cy - py;
     const double dist = fast_norm(rx, ry);
     const double x2 = fmin(2.0 * ((n - 1.0) * 0.5 - dist), 700.0);  // -2 (dist - maxd)
-    const double soft = k.f_coherence * sfwm::rcp_nr(1.0 + sfwm::exp_fast(k.pc, x2));
+    const double soft = c.f_coherence * sfwm::rcp_nr(1.0 + sfwm::exp_fast(k.pc, x2));
     fx = fma(rx, soft, fx);
     fy = fma(ry, soft, fy);
   }
@@ -623,12 +670,11 @@ __device__ double2 group_force(const sfm_consts<R> &k, const lds_layout &s, int 
   for (int m = m0; m < m1; ++m) {
     const int b = s.gmem[m];
     if (b == i) continue;
-    const double2 pb = s.pos[g * A + b];
-    const double dx = px - pb.x, dy = py - pb.y, rr = ra + s.rad[b];
+    const double dx = px - s.px[g * A + b], dy = py - s.py[g * A + b], rr = ra + s.rad[b];
     if (fma(dx, dx, dy * dy) < rr * rr) { rx += dx; ry += dy; }
   }
-  fx = fma(rx, k.f_repulsion, fx);
-  fy = fma(ry, k.f_repulsion, fy);
+  fx = fma(rx, c.f_repulsion, fx);
+  fy = fma(ry, c.f_repulsion, fy);
   return double2{fx, fy};
 }
 
@@ -639,26 +685,15 @@ template <> __device__ __forceinline__ const sfw_force_k<float> &force_k<float>(
 template <typename R, bool PIN_ALL> __device__ __forceinline__ sfm_consts<R> make_consts(const sfw_launch &L) {
   const sfw_force_k<R> &f = force_k<R>(L);
   sfm_consts<R> k;
-  // The pair loop reads 33 distinct FP64 constants (19 polynomial coefficients, the range-reduction
-  // and fold constants, these six): 66 SGPRs, more than the allocator has left next to the
-  // kernel arguments, and it then reloads spilled ones with v_readlane inside the loop.  The VGPR
-  // file has the room, so these stay in vector registers (all six in the flat kernel, four in
-  // the register-resident one, which has to stay within 80 VGPRs for six waves per SIMD).
+  // The pair loop reads ~30 distinct FP64 constants (19 polynomial coefficients, the range-reduction and fold
+  // constants, these five): more SGPRs than the allocator has next to the loop's addresses and counters, so
+  // these stay in vector registers (all five in the flat kernel, three in the register-resident one, which has to
+  // stay within 80 VGPRs for six waves per SIMD).
   k.lambda = sfwm::vgpr_const(f.lambda);
-  k.gamma2 = sfwm::vgpr_const(f.gamma2);
   k.neg_inv_gamma = sfwm::vgpr_const(f.neg_inv_gamma);
-  k.neg_n2 = PIN_ALL ? sfwm::vgpr_const(f.neg_n2) : f.neg_n2;
-  k.neg_n_prime2 = sfwm::vgpr_const(f.neg_n_prime2);
-  k.f_social = PIN_ALL ? sfwm::vgpr_const(f.f_social) : f.f_social;
-  k.f_obstacle = f.f_obstacle;
-  k.inv_sigma = f.inv_sigma;
-  k.f_desired = L.k.f_desired;
-  k.inv_tau = L.k.inv_tau;
-  k.dt = L.dt;
-  k.rr = L.k.rr;
-  k.f_gaze = L.p.sfm_force_factor_group_gaze;
-  k.f_coherence = L.p.sfm_force_factor_group_coherence;
-  k.f_repulsion = L.p.sfm_force_factor_group_repulsion;
+  k.ln_f_social = PIN_ALL ? sfwm::vgpr_const(f.ln_f_social) : f.ln_f_social;
+  k.c_vel = sfwm::vgpr_const(f.c_vel);
+  k.c_ang = PIN_ALL ? sfwm::vgpr_const(f.c_ang) : f.c_ang;
   return k;
 }
 
@@ -667,9 +702,9 @@ template <typename R, bool PIN_ALL> __device__ __forceinline__ sfm_consts<R> mak
 // desired+obstacle force.  F = total force on the agent at the pre-step state
 // (for the robot: its social force only).  Returns this slot's social work.
 template <typename R>
-__device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_layout &s, const sfw_robot_step &rs,
-                                             const agent_k &ak, int step, int i, int g, int sl, int O, double inv_O,
-                                             int robot_id, double &px, double &py, double &vx, double &vy, double Fx,
+__device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const agent_consts &c, const lds_layout &s,
+                                             const sfw_robot_step &rs, const agent_k &ak, int step, int i, int g,
+                                             int sl, double &px, double &py, double &vx, double &vy, double Fx,
                                              double Fy, double &nfx, double &nfy) {
   double work = 0.0;
   const bool robot = (i == 0);
@@ -679,8 +714,8 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_l
     work = fast_norm(Fx, Fy);  // Wr, social part (ref :681-682): the robot's social force at the pre-step state
   } else {
     // lightsfm updatePosition, non-teleoperated branch
-    vx = fma(Fx, k.dt, vx);
-    vy = fma(Fy, k.dt, vy);
+    vx = fma(Fx, c.dt, vx);
+    vy = fma(Fy, c.dt, vy);
     double rsp, sp;
     sfwm::rsqrt_sqrt(fmax(fma(vx, vx, vy * vy), 1e-300), rsp, sp);
     if (sp > ak.dv) {
@@ -688,8 +723,8 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_l
       vx *= sc;
       vy *= sc;
     }
-    px = fma(vx, k.dt, px);
-    py = fma(vy, k.dt, py);
+    px = fma(vx, c.dt, px);
+    py = fma(vy, c.dt, py);
     int hg = s.hasgoal[sl];
     if (hg) {
       const double ex = ak.gx - px, ey = ak.gy - py;
@@ -698,22 +733,22 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const lds_l
     }
     // dynamic collision with the robot's post-step pose (ref :613-627)
     const double cx = rs.x - px, cy = rs.y - py;
-    if (cx * cx + cy * cy <= k.rr) s.dead[g] = 2 + step;  // >= 2: rejected by contact at `step`
+    if (cx * cx + cy * cy <= c.rr) s.dead[g] = 2 + step;  // >= 2: rejected by contact at `step`
     // Wp (ref :692-699): force the post-step robot alone exerts on this person
-    if (ak.id != robot_id) {
+    if (ak.id != c.robot_id) {
       R qx, qy;
       pair_force_state<R>(k, px, py, vx, vy, rs.x, rs.y, rs.vx, rs.vy, qx, qy);
       work = fast_norm(static_cast<double>(qx), static_cast<double>(qy));
     }
     // desired force at the new state: with the obstacle term below, the next step's starting force
-    desired_force<R>(k, px, py, vx, vy, hg != 0, ak.gx, ak.gy, ak.gr, ak.dv, nfx, nfy);
+    desired_force(c, px, py, vx, vy, hg != 0, ak.gx, ak.gy, ak.gr, ak.dv, nfx, nfy);
   }
-  if (O > 0) {
+  if (c.O > 0) {
     // Obstacle term, ONE loop over the laser points for every lane of the wave: the robot needs it at its
     // pre-step position (Wr's obstacle part), a person at its new position.  A call in each branch would run
     // the O-point loop twice per wave (the branches diverge): measured 55 instead of 30 issue slots per point.
     double ox, oy;
-    obstacle_force<R>(k, s.obs, O, inv_O, px, py, ak.rad, ox, oy);
+    obstacle_force<R>(k, c, s.obs, px, py, ak.rad, ox, oy);
     if (robot) {
       work += fast_norm(ox, oy);
     } else {
@@ -792,23 +827,31 @@ __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout
   return any_live;
 }
 
-// Write the per-sample results: cost = base + w_s * social_work (ref :663-667).
-__device__ __forceinline__ void finish_wave(const sfw_launch &L, const lds_layout &s, int lane, int G, int Gn,
-                                            int GA, int64_t first_local, double sw_acc) {
-  const int A = L.A;
+// Write the per-sample results: cost = base + w_s * social_work (ref :663-667).  The output pointers are read
+// through late_args(): they are needed once, after the rollout.
+__device__ __forceinline__ void finish_wave(const lds_layout &s, int lane, int G, int Gn, int64_t first_local,
+                                            double sw_acc) {
+  const late_launch La = late_args();
+  const int A = La->A;
+  const double social_weight = La->p.social_weight;
+  double *const costs = La->costs;
+  const double *const base_cost = La->base_cost;
+  int32_t *const status = La->status, *const coll_step = La->coll_step;
+  const int64_t t0 = La->chunk_begin + first_local;
+  auto put = [&](int g, double v) {
+    const int64_t t = t0 + g;
+    const int d = s.dead[g];
+    if (d == 0) costs[t] = base_cost[t] + social_weight * v;
+    else if (d >= 2) {
+      costs[t] = SFW_COST_INVALID;
+      status[t] = SFW_ST_INVALID;
+      if (coll_step) coll_step[t] = d - 2;
+    }
+  };
   if (G == 1) {
     double v = sw_acc;
     for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-    if (lane == 0) {
-      const int64_t t = L.chunk_begin + first_local;
-      const int d = s.dead[0];
-      if (d == 0) L.costs[t] = L.base_cost[t] + L.p.social_weight * v;
-      else if (d >= 2) {
-        L.costs[t] = SFW_COST_INVALID;
-        L.status[t] = SFW_ST_INVALID;
-        if (L.coll_step) L.coll_step[t] = d - 2;
-      }
-    }
+    if (lane == 0) put(0, v);
   } else {
     // G > 1 (GA <= 64): per-slot sums were written to swp[]; every sample is reduced
     // with the SAME 64-lane shuffle tree as the G == 1 case (lanes >= A contribute 0),
@@ -817,39 +860,32 @@ __device__ __forceinline__ void finish_wave(const sfw_launch &L, const lds_layou
     for (int g = 0; g < Gn; ++g) {
       double v = (lane < A) ? s.swp[g * A + lane] : 0.0;
       for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-      if (lane == 0) {
-        const int64_t t = L.chunk_begin + first_local + g;
-        const int d = s.dead[g];
-        if (d == 0) L.costs[t] = L.base_cost[t] + L.p.social_weight * v;
-        else if (d >= 2) {
-          L.costs[t] = SFW_COST_INVALID;
-          L.status[t] = SFW_ST_INVALID;
-          if (L.coll_step) L.coll_step[t] = d - 2;
-        }
-      }
+      if (lane == 0) put(g, v);
     }
   }
-  (void)GA;
+}
+
+// LDS word at a byte offset of the wave's allocation.  The K2 kernels have no static __shared__ data, so their
+// dynamic allocation starts at LDS address 0 and an offset IS the address: forming it from `smem` instead costs a
+// v_add with the (link-time zero) base per address register in the pair loop.
+template <typename T> __device__ __forceinline__ T &lds_at(char *, unsigned byte_off) {
+  return *(T *)reinterpret_cast<__attribute__((address_space(3))) T *>(static_cast<uintptr_t>(byte_off));
 }
 
 // ---------------------------------------------------------------------------
 // K2, register-resident form: every lane owns NS agent slots (slot = r*64+lane,
-// slot -> (sample g, agent i)) whose state and force accumulator stay in VGPRs
-// for the whole rollout; LDS holds the copy the partners read.  The unordered
+// slot -> (sample g, agent i)) whose force accumulator and social-work sum stay in
+// VGPRs for the whole rollout; LDS holds the state the partners read.  The unordered
 // pairs are walked as a half ring: in row k every agent i meets
 // j = (i + k + 1) mod A, so within a row each agent is `i` once and `j` once:
 // the i-side force accumulates in registers, the j-side goes through one LDS
 // atomic whose addresses are all distinct within the instruction.
 // ---------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ T &lds_at(char *base, int byte_off) {
-  return *reinterpret_cast<T *>(base + byte_off);
-}
-
 template <typename R, int NS, bool GROUPS>
 __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social_kernel(const sfw_launch L, const int G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CAP = WAVE * NS;             // GA <= CAP: state arrays at compile-time distances
-  constexpr int VEL = 16 * CAP, FRJ = 32 * CAP;  // byte offsets of vel[] / frj[] from pos[]
+  constexpr int CAP = WAVE * NS;  // GA <= CAP: state planes at compile-time distances
+  constexpr int PY = 8 * CAP, VX = 16 * CAP, VY = 24 * CAP, FJX = 32 * CAP, FJY = 40 * CAP;  // byte offsets from px[]
   const int lane = threadIdx.x;
   const int A = L.A, O = L.O;
   const int GA = G * A;
@@ -860,10 +896,10 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   const int Gn = remain < G ? static_cast<int>(remain) : G;
   const int step_begin = L.step_begin, step_end = L.step_end;
   const sfm_consts<R> k = make_consts<R, false>(L);
-  const double inv_O = L.k.inv_O;
+  constexpr bool F32 = sizeof(R) == 4;
   if (!stage_wave<GROUPS, true>(L, s, lane, G, Gn, first_local)) {
     // nothing to integrate; items that inherit a contact still pass the verdict on
-    if (L.phase == SFW_PHASE_SUFFIX) finish_wave(L, s, lane, G, Gn, GA, first_local, 0.0);
+    if (L.phase == SFW_PHASE_SUFFIX) finish_wave(s, lane, G, Gn, first_local, 0.0);
     if (L.phase == SFW_PHASE_PREFIX && lane < Gn) L.out_dead[first_local + lane] = s.dead[lane];
     return;
   }
@@ -872,99 +908,99 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   int sl_[NS], g_[NS], i_[NS];
   bool ok_[NS];
   // Registers hold only the force accumulator and the social-work sum of a slot; position and
-  // velocity are re-read from LDS where needed (two more ds_read_b128 per pair, LDS has the
-  // headroom): with them in VGPRs the NS = 1 kernel needs 87 registers, i.e. scratch spills
-  // under the 80 that six waves per SIMD allow.
+  // velocity are re-read from LDS where needed (LDS has the headroom): with them in VGPRs the
+  // NS = 1 kernel needs 87 registers, i.e. scratch spills under the 80 that six waves per SIMD allow.
   double fx[NS], fy[NS], sw[NS];
+  {
+    const agent_consts c0 = load_agent_consts(late_args(), F32);
 #pragma unroll
-  for (int r = 0; r < NS; ++r) {
-    double px[NS], py[NS], vx[NS], vy[NS];
-    const int sl = r * WAVE + lane;
-    ok_[r] = sl < GA;
-    const int slc = ok_[r] ? sl : 0;
-    g_[r] = (G == 1) ? 0 : slc / A;
-    i_[r] = slc - g_[r] * A;
-    sl_[r] = slc;
-    const int i = i_[r];
-    fx[r] = fy[r] = sw[r] = 0.0;
-    if (L.resume) {  // resume from the record of the item's (parent) class
-      if (ok_[r] && g_[r] < Gn) {
-        const sfw_cls_agent c = L.in_state[source_class_of_item(L, first_local + g_[r]) * A + i];
-        s.pos[sl] = double2{c.px, c.py};
-        s.vel[sl] = double2{c.vx, c.vy};
-        s.frj[sl] = double2{0.0, 0.0};
-        s.hasgoal[sl] = c.hasgoal;
-        fx[r] = c.fx;
-        fy[r] = c.fy;
-        sw[r] = c.sw;
-      } else if (ok_[r]) {
-        s.pos[sl] = s.vel[sl] = s.frj[sl] = double2{0.0, 0.0};
-        s.hasgoal[sl] = 0;
-      }
-      continue;
-    }
-    px[r] = L.agent_pos[2 * i];
-    py[r] = L.agent_pos[2 * i + 1];
-    vx[r] = L.agent_vel[2 * i];
-    vy[r] = L.agent_vel[2 * i + 1];
-    if (ok_[r]) {
-      const int hg = L.agent_c[i].has_goal;
-      s.pos[sl] = double2{px[r], py[r]};
-      s.vel[sl] = double2{vx[r], vy[r]};
-      s.frj[sl] = double2{0.0, 0.0};
-      s.hasgoal[sl] = hg;
-      if (i != 0) {
-        const double2 gl = s.goal[i];
-        desired_force<R>(k, px[r], py[r], vx[r], vy[r], hg != 0, gl.x, gl.y, s.gr[i], s.dv[i], fx[r], fy[r]);
-        if (O > 0) {
-          double ox, oy;
-          obstacle_force<R>(k, s.obs, O, inv_O, px[r], py[r], s.rad[i], ox, oy);
-          fx[r] += ox;
-          fy[r] += oy;
+    for (int r = 0; r < NS; ++r) {
+      const int sl = r * WAVE + lane;
+      ok_[r] = sl < GA;
+      const int slc = ok_[r] ? sl : 0;
+      g_[r] = (G == 1) ? 0 : slc / A;
+      i_[r] = slc - g_[r] * A;
+      sl_[r] = slc;
+      const int i = i_[r];
+      fx[r] = fy[r] = sw[r] = 0.0;
+      if (L.resume) {  // resume from the record of the item's (parent) class
+        if (ok_[r] && g_[r] < Gn) {
+          const sfw_cls_agent c = L.in_state[source_class_of_item(L, first_local + g_[r]) * A + i];
+          s.px[sl] = c.px;
+          s.py[sl] = c.py;
+          s.vx[sl] = c.vx;
+          s.vy[sl] = c.vy;
+          s.fjx[sl] = s.fjy[sl] = 0.0;
+          s.hasgoal[sl] = c.hasgoal;
+          fx[r] = c.fx;
+          fy[r] = c.fy;
+          sw[r] = c.sw;
+        } else if (ok_[r]) {
+          s.px[sl] = s.py[sl] = s.vx[sl] = s.vy[sl] = s.fjx[sl] = s.fjy[sl] = 0.0;
+          s.hasgoal[sl] = 0;
         }
+        continue;
       }
-      if (L.agent_rest) {  // pairs at exact relative rest in the handed-over state (robot included)
-        fx[r] += L.agent_rest[2 * i];
-        fy[r] += L.agent_rest[2 * i + 1];
+      if (ok_[r]) {
+        const double px = L.agent_pos[2 * i], py = L.agent_pos[2 * i + 1];
+        const double vx = L.agent_vel[2 * i], vy = L.agent_vel[2 * i + 1];
+        const int hg = L.agent_c[i].has_goal;
+        s.px[sl] = px;
+        s.py[sl] = py;
+        s.vx[sl] = vx;
+        s.vy[sl] = vy;
+        s.fjx[sl] = s.fjy[sl] = 0.0;
+        s.hasgoal[sl] = hg;
+        if (i != 0) {
+          const double2 gl = s.goal[i];
+          desired_force(c0, px, py, vx, vy, hg != 0, gl.x, gl.y, s.gr[i], s.dv[i], fx[r], fy[r]);
+          if (O > 0) {
+            double ox, oy;
+            obstacle_force<R>(k, c0, s.obs, px, py, s.rad[i], ox, oy);
+            fx[r] += ox;
+            fy[r] += oy;
+          }
+        }
+        if (L.agent_rest) {  // pairs at exact relative rest in the handed-over state (robot included)
+          fx[r] += L.agent_rest[2 * i];
+          fy[r] += L.agent_rest[2 * i + 1];
+        }
       }
     }
   }
   __syncthreads();
   // Group forces belong to the force at the CURRENT state, so they are added to
   // the starting force after every state update (and once here for step 0).
-  auto add_group_forces = [&]() {
+  auto add_group_forces = [&](const agent_consts &c) {
     for (int q = lane; q < G * NG; q += WAVE) s.gcen[q] = double2{0.0, 0.0};
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NS; ++r)
       if (ok_[r] && s.grp[i_[r]] >= 0) {
-        const double2 p = s.pos[sl_[r]];
-        atomicAdd(&s.gcen[g_[r] * NG + s.grp[i_[r]]].x, p.x);
-        atomicAdd(&s.gcen[g_[r] * NG + s.grp[i_[r]]].y, p.y);
+        atomicAdd(&s.gcen[g_[r] * NG + s.grp[i_[r]]].x, s.px[sl_[r]]);
+        atomicAdd(&s.gcen[g_[r] * NG + s.grp[i_[r]]].y, s.py[sl_[r]]);
       }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NS; ++r)
       if (ok_[r] && i_[r] != 0) {
-        const double2 p = s.pos[sl_[r]];
-        const double2 gf = group_force<R>(k, s, NG, g_[r], A, i_[r], sl_[r], p.x, p.y);
+        const double2 gf = group_force<R>(k, c, s, NG, g_[r], A, i_[r], sl_[r], s.px[sl_[r]], s.py[sl_[r]]);
         fx[r] += gf.x;
         fy[r] += gf.y;
       }
   };
   if constexpr (GROUPS) {
-    if (!L.resume) add_group_forces();  // a class record's force already has them
+    if (!L.resume) add_group_forces(load_agent_consts(late_args(), F32));  // a class record's force already has them
   }
 
   const int rows = A / 2;            // half ring; for even A the last row is half length
   const bool even = (A & 1) == 0;
-  const int robot_id = L.agent_c[0].id;
-  // byte offset (within pos[]) of the partner each slot meets next, and its wrap bound:
+  // byte offset (within a plane) of the partner each slot meets next, and its wrap bound:
   // the partner walks i+1, i+2, ... inside the slot's own sample
   int jo_[NS], hi_[NS];
 #pragma unroll
-  for (int r = 0; r < NS; ++r) hi_[r] = 16 * (sl_[r] - i_[r] + A);
-  const int wrap = 16 * A;
+  for (int r = 0; r < NS; ++r) hi_[r] = 8 * (sl_[r] - i_[r] + A);
+  const int wrap = 8 * A;
 
   for (int step = step_begin; step < step_end; ++step) {
     // This step's robot records (32 B per sample, contiguous) go from the K1 table straight to
@@ -983,25 +1019,25 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
       }
     // ---- pair pass: social forces at the pre-step state -------------------
 #pragma unroll
-    for (int r = 0; r < NS; ++r) jo_[r] = 16 * sl_[r];
+    for (int r = 0; r < NS; ++r) jo_[r] = 8 * sl_[r];
     for (int row = 0; row < rows; ++row) {
       const bool half = even && (row == rows - 1);
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        int jo = jo_[r] + 16;
+        int jo = jo_[r] + 8;
         jo = (jo >= hi_[r]) ? jo - wrap : jo;
         jo_[r] = jo;
         if (ok_[r] && !(half && i_[r] >= rows)) {
-          const int io = 16 * sl_[r];
-          const double2 pi = lds_at<double2>(smem, io), vi = lds_at<double2>(smem, io + VEL);
-          const double2 pj = lds_at<double2>(smem, jo), vj = lds_at<double2>(smem, jo + VEL);
+          const int io = 8 * sl_[r];
           R qx, qy;
-          pair_force_state<R>(k, pi.x, pi.y, vi.x, vi.y, pj.x, pj.y, vj.x, vj.y, qx, qy);
+          pair_force_state<R>(k, lds_at<double>(smem, io), lds_at<double>(smem, io + PY), lds_at<double>(smem, io + VX),
+                              lds_at<double>(smem, io + VY), lds_at<double>(smem, jo), lds_at<double>(smem, jo + PY),
+                              lds_at<double>(smem, jo + VX), lds_at<double>(smem, jo + VY), qx, qy);
           fx[r] += static_cast<double>(qx);
           fy[r] += static_cast<double>(qy);
           // the partner receives -q: accumulated with the opposite sign, subtracted in the agent pass
-          atomicAdd(&lds_at<double>(smem, jo + FRJ), static_cast<double>(qx));
-          atomicAdd(&lds_at<double>(smem, jo + FRJ + 8), static_cast<double>(qy));
+          atomicAdd(&lds_at<double>(smem, jo + FJX), static_cast<double>(qx));
+          atomicAdd(&lds_at<double>(smem, jo + FJY), static_cast<double>(qy));
         }
       }
     }
@@ -1009,48 +1045,54 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     __syncthreads();
 
     // ---- per-agent pass ---------------------------------------------------
+    const agent_consts c = load_agent_consts(late_args(), F32);
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
       if (ok_[r] && s.dead[g_[r]] == 0) {
         const int sl = sl_[r];
         const sfw_robot_step rs = s.rsb[g_[r]];
-        const double2 Fj = s.frj[sl];
-        double2 p = s.pos[sl], v = s.vel[sl];
+        double px = s.px[sl], py = s.py[sl], vx = s.vx[sl], vy = s.vy[sl];
         double nfx, nfy;
-        sw[r] += agent_step<R>(k, s, rs, agent_k_lds(s, i_[r]), step, i_[r], g_[r], sl, O, inv_O, robot_id, p.x, p.y,
-                               v.x, v.y, fx[r] - Fj.x, fy[r] - Fj.y, nfx, nfy);
+        sw[r] += agent_step<R>(k, c, s, rs, agent_k_lds(s, i_[r]), step, i_[r], g_[r], sl, px, py, vx, vy,
+                               fx[r] - s.fjx[sl], fy[r] - s.fjy[sl], nfx, nfy);
         fx[r] = nfx;
         fy[r] = nfy;
         if (i_[r] == 0) {  // the robot does not move by SFM: post-step record (ref :600, :604 robot-local twist)
           const sfw_robot_step r2 = s.rsb[g_[r]];
-          p = double2{r2.x, r2.y};
-          v = double2{r2.vx, r2.vy};
+          px = r2.x;
+          py = r2.y;
+          vx = r2.vx;
+          vy = r2.vy;
         }
-        s.pos[sl] = p;
-        s.vel[sl] = v;
-        s.frj[sl] = double2{0.0, 0.0};
+        s.px[sl] = px;
+        s.py[sl] = py;
+        s.vx[sl] = vx;
+        s.vy[sl] = vy;
+        s.fjx[sl] = 0.0;
+        s.fjy[sl] = 0.0;
       }
     }
     __syncthreads();
     bool any_live = false;
     for (int g = 0; g < G; ++g) any_live |= (s.dead[g] == 0);
     if (!any_live) break;
-    if constexpr (GROUPS) add_group_forces();
+    if constexpr (GROUPS) add_group_forces(c);
   }
 
-  if (L.phase == SFW_PHASE_PREFIX) {  // leave the class records
+  const late_launch Le = late_args();
+  if (Le->phase == SFW_PHASE_PREFIX) {  // leave the class records
+    sfw_cls_agent *const out_state = Le->out_state;
 #pragma unroll
     for (int r = 0; r < NS; ++r)
       if (ok_[r] && g_[r] < Gn) {
-        const double2 p = s.pos[sl_[r]], v = s.vel[sl_[r]];
         sfw_cls_agent c;
-        c.px = p.x; c.py = p.y; c.vx = v.x; c.vy = v.y;
+        c.px = s.px[sl_[r]]; c.py = s.py[sl_[r]]; c.vx = s.vx[sl_[r]]; c.vy = s.vy[sl_[r]];
         c.fx = fx[r]; c.fy = fy[r]; c.sw = sw[r];
         c.hasgoal = s.hasgoal[sl_[r]];
         c.pad = 0;
-        L.out_state[(first_local + g_[r]) * A + i_[r]] = c;
+        out_state[(first_local + g_[r]) * A + i_[r]] = c;
       }
-    if (lane < Gn) L.out_dead[first_local + lane] = s.dead[lane];
+    if (lane < Gn) Le->out_dead[first_local + lane] = s.dead[lane];
     return;
   }
   double sw_acc = 0.0;
@@ -1059,7 +1101,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     if (G == 1) sw_acc += ok_[r] ? sw[r] : 0.0;
     else if (ok_[r]) s.swp[sl_[r]] = sw[r];
   }
-  finish_wave(L, s, lane, G, Gn, GA, first_local, sw_acc);
+  finish_wave(s, lane, G, Gn, first_local, sw_acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -1071,26 +1113,46 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
 // each accumulator's summation order is a function of u only.
 //
 // The u -> (i, j) map is the same for every step of every sample, so it is not
-// recomputed: sfw_pair_table_kernel writes it once per agent set as packed LDS
-// byte offsets (16*i | 16*j << 16, padded to a multiple of 64 with PAIR_NONE) and
-// the pair loop reads one coalesced dword per lane per iteration (L2-resident,
-// shared by all waves).  With the state arrays CAP records apart (CAP = 0: A,
-// run-time) the loop's integer work is two unpack instructions.
+// recomputed: sfw_pair_table_kernel writes it once per agent set as two uint16
+// arrays of plane byte offsets (8*i, 8*j), padded to a multiple of 64 with the
+// DUMMY slot 8*A (a record behind the last agent: its pair evaluates on zeros and
+// lands in accumulators nobody reads, so the loop needs no lane predicate).  A
+// lane's entries arrive as two zero-extending global_load_ushort from a
+// wave-uniform base (scalar address arithmetic, no unpacking): the pair loop
+// spends no VALU issue on indices.  The loads are written as asm, one iteration
+// ahead, into two alternating register pairs (loop unrolled by two: no copies).
 // ---------------------------------------------------------------------------
-constexpr uint32_t PAIR_NONE = 0xFFFFFFFFu;
-
-__global__ void __launch_bounds__(256) sfw_pair_table_kernel(uint32_t *tab, int A, int n_entries) {
+__global__ void __launch_bounds__(256) sfw_pair_table_kernel(uint16_t *tab, int A, int n_entries) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_entries) return;
   const int P = A * (A - 1) / 2;
-  uint32_t e = PAIR_NONE;
+  int i = A, j = A;  // dummy slot
   if (u < P) {
-    const int row = u / A, i = u - row * A;
-    int j = i + row + 1;
+    const int row = u / A;
+    i = u - row * A;
+    j = i + row + 1;
     j = (j >= A) ? j - A : j;
-    e = static_cast<uint32_t>(16 * i) | (static_cast<uint32_t>(16 * j) << 16);
   }
-  tab[u] = e;
+  tab[u] = static_cast<uint16_t>(8 * i);
+  tab[n_entries + u] = static_cast<uint16_t>(8 * j);
+}
+
+__device__ __forceinline__ void load_pair_entries(const uint16_t *ti, const uint16_t *tj, uint32_t lane_off, uint32_t &io,
+                                                  uint32_t &jo) {
+#ifdef SFW_DBG_C_LOADS
+  io = ti[lane_off / 2];
+  jo = tj[lane_off / 2];
+  return;
+#endif
+  // s_nop 4: the table addresses may have just been reloaded from a spill lane (v_readlane: VALU writes an SGPR), and a
+  // VMEM instruction reading such an SGPR needs 5 wait states — the compiler's hazard recogniser does not look inside
+  // an asm block (found as a memory fault that only showed with many waves per SIMD)
+  asm volatile("s_nop 4\n\tglobal_load_ushort %0, %2, %3\n\tglobal_load_ushort %1, %2, %4"
+               : "=&v"(io), "=&v"(jo)
+               : "v"(lane_off), "s"(ti), "s"(tj));
+}
+__device__ __forceinline__ void wait_pair_entries(uint32_t &io, uint32_t &jo) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(io), "+v"(jo));
 }
 
 #ifndef SFW_FLAT_WAVES
@@ -1103,15 +1165,16 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
   const int lane = threadIdx.x;
   const int A = L.A, O = L.O;
   const int NG = GROUPS ? L.NG : 0;
-  const int cap = CAP > 0 ? CAP : A;
-  const int VEL = 16 * cap, FRJ = 32 * cap, FRC = 48 * cap;  // byte offsets from pos[] (immediates when CAP > 0)
+  const int cap = CAP > 0 ? CAP : ((A + 2) & ~1);  // > A: the dummy slot of the padded pair table
+  const int PY = 8 * cap, VX = 16 * cap, VY = 24 * cap, FJX = 32 * cap, FJY = 40 * cap, FCX = 48 * cap,
+            FCY = 56 * cap;  // byte offsets from px[] (immediates when CAP > 0)
   const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, GROUPS, true);
   const int64_t first_local = xcd_contiguous(blockIdx.x, gridDim.x);
   const sfm_consts<R> k = make_consts<R, true>(L);
-  const double inv_O = L.k.inv_O;
+  constexpr bool F32 = sizeof(R) == 4;
   const int step_begin = L.step_begin, step_end = L.step_end;
   if (!stage_wave<GROUPS, GROUPS>(L, s, lane, 1, 1, first_local)) {
-    if (L.phase == SFW_PHASE_SUFFIX) finish_wave(L, s, lane, 1, 1, A, first_local, 0.0);  // inherited contact
+    if (L.phase == SFW_PHASE_SUFFIX) finish_wave(s, lane, 1, 1, first_local, 0.0);  // inherited contact
     if (L.phase == SFW_PHASE_PREFIX && lane == 0) L.out_dead[first_local] = s.dead[0];
     return;
   }
@@ -1121,29 +1184,34 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
     const sfw_cls_agent *rec = L.in_state + source_class_of_item(L, first_local) * A;
     for (int sl = lane; sl < A; sl += WAVE) {
       const sfw_cls_agent c = rec[sl];
-      s.pos[sl] = double2{c.px, c.py};
-      s.vel[sl] = double2{c.vx, c.vy};
+      s.px[sl] = c.px;
+      s.py[sl] = c.py;
+      s.vx[sl] = c.vx;
+      s.vy[sl] = c.vy;
       s.hasgoal[sl] = c.hasgoal;
       s.swp[sl] = c.sw;
-      s.frc[sl] = double2{c.fx, c.fy};
-      s.frj[sl] = double2{0.0, 0.0};
+      s.fcx[sl] = c.fx;
+      s.fcy[sl] = c.fy;
+      s.fjx[sl] = s.fjy[sl] = 0.0;
     }
   } else {
+    const agent_consts c0 = load_agent_consts(late_args(), F32);
     for (int sl = lane; sl < A; sl += WAVE) {
       const double px = L.agent_pos[2 * sl], py = L.agent_pos[2 * sl + 1];
       const double vx = L.agent_vel[2 * sl], vy = L.agent_vel[2 * sl + 1];
       const sfw_agent_const c = L.agent_c[sl];
-      s.pos[sl] = double2{px, py};
-      s.vel[sl] = double2{vx, vy};
+      s.px[sl] = px;
+      s.py[sl] = py;
+      s.vx[sl] = vx;
+      s.vy[sl] = vy;
       s.hasgoal[sl] = c.has_goal;
       s.swp[sl] = 0.0;
       double fx = 0.0, fy = 0.0;
       if (sl != 0) {
-        desired_force<R>(k, px, py, vx, vy, c.has_goal != 0, c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity,
-                         fx, fy);
+        desired_force(c0, px, py, vx, vy, c.has_goal != 0, c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity, fx, fy);
         if (O > 0) {
           double ox, oy;
-          obstacle_force<R>(k, s.obs, O, inv_O, px, py, c.radius, ox, oy);
+          obstacle_force<R>(k, c0, s.obs, px, py, c.radius, ox, oy);
           fx += ox;
           fy += oy;
         }
@@ -1152,100 +1220,137 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
         fx += L.agent_rest[2 * sl];
         fy += L.agent_rest[2 * sl + 1];
       }
-      s.frc[sl] = double2{fx, fy};
-      s.frj[sl] = double2{0.0, 0.0};
+      s.fcx[sl] = fx;
+      s.fcy[sl] = fy;
+      s.fjx[sl] = s.fjy[sl] = 0.0;
     }
   }
+  if (lane == 0) {  // the dummy slot: finite state, accumulators nobody reads
+    s.px[A] = s.py[A] = s.vx[A] = s.vy[A] = 0.0;
+    s.fcx[A] = s.fcy[A] = s.fjx[A] = s.fjy[A] = 0.0;
+  }
   __syncthreads();
-  auto add_group_forces = [&]() {
+  auto add_group_forces = [&](const agent_consts &c) {
     for (int q = lane; q < NG; q += WAVE) s.gcen[q] = double2{0.0, 0.0};
     __syncthreads();
     for (int sl = lane; sl < A; sl += WAVE)
       if (s.grp[sl] >= 0) {
-        const double2 p = s.pos[sl];
-        atomicAdd(&s.gcen[s.grp[sl]].x, p.x);
-        atomicAdd(&s.gcen[s.grp[sl]].y, p.y);
+        atomicAdd(&s.gcen[s.grp[sl]].x, s.px[sl]);
+        atomicAdd(&s.gcen[s.grp[sl]].y, s.py[sl]);
       }
     __syncthreads();
     for (int sl = lane; sl < A; sl += WAVE)
       if (sl != 0) {
-        const double2 p = s.pos[sl];
-        const double2 gf = group_force<R>(k, s, NG, 0, A, sl, sl, p.x, p.y);
-        double2 f = s.frc[sl];
-        f.x += gf.x;
-        f.y += gf.y;
-        s.frc[sl] = f;
+        const double2 gf = group_force<R>(k, c, s, NG, 0, A, sl, sl, s.px[sl], s.py[sl]);
+        s.fcx[sl] += gf.x;
+        s.fcy[sl] += gf.y;
       }
     __syncthreads();
   };
   if constexpr (GROUPS) {
-    if (!L.resume) add_group_forces();  // a class record's force already has them
+    if (!L.resume) add_group_forces(load_agent_consts(late_args(), F32));  // a class record's force already has them
   }
 
   const int P = A * (A - 1) / 2;  // unordered pairs
   const int n_it = (P + WAVE - 1) / WAVE;
-  const int robot_id = L.agent_c[0].id;
+  const uint16_t *const tab_i = L.pair_tab, *const tab_j = L.pair_tab + static_cast<size_t>(n_it) * WAVE;
+  const uint32_t lane_off = 2u * static_cast<uint32_t>(lane);
+
+  // robot record of a step: lanes 0 and 1 bring 16 bytes each from the K1 table straight to LDS
+  auto fetch_robot = [&](const sfw_robot_step *rstep, int64_t stride, int st, int buf) {
+#ifdef SFW_DBG_PLAIN_ROBOT
+    if (lane == 0) s.rsb[buf] = rstep[static_cast<int64_t>(st) * stride + rsample];
+    return;
+#endif
+    if (lane < 2) {
+      const char *src = reinterpret_cast<const char *>(rstep + static_cast<int64_t>(st) * stride + rsample) + 16 * lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(s.rsb + buf)), 16,
+                                       0, 0);
+    }
+  };
+  if (step_begin < step_end) fetch_robot(L.rstep, L.rstep_stride, step_begin, step_begin & 1);
+
+  // one pair per lane: both agents from LDS, the force into both agents' accumulators
+  auto pair_at = [&](uint32_t io, uint32_t jo) {
+    R qx, qy;
+    pair_force_state<R>(k, lds_at<double>(smem, io), lds_at<double>(smem, io + PY), lds_at<double>(smem, io + VX),
+                        lds_at<double>(smem, io + VY), lds_at<double>(smem, jo), lds_at<double>(smem, jo + PY),
+                        lds_at<double>(smem, jo + VX), lds_at<double>(smem, jo + VY), qx, qy);
+    atomicAdd(&lds_at<double>(smem, io + FCX), static_cast<double>(qx));
+    atomicAdd(&lds_at<double>(smem, io + FCY), static_cast<double>(qy));
+    // j receives -q: accumulated with the opposite sign, subtracted in the agent pass
+    atomicAdd(&lds_at<double>(smem, jo + FJX), static_cast<double>(qx));
+    atomicAdd(&lds_at<double>(smem, jo + FJY), static_cast<double>(qy));
+  };
 
   for (int step = step_begin; step < step_end; ++step) {
-    const uint32_t *row = L.pair_tab;  // wave-uniform: scalar base + constant lane offset
-    uint32_t next = n_it > 0 ? row[lane] : PAIR_NONE;
-    for (int it = 0; it < n_it; ++it) {
-      const uint32_t e = next;
-      row += WAVE;
-      if (it + 1 < n_it) next = row[lane];  // in flight during this pair's arithmetic
-      if (e != PAIR_NONE) {
-        const int io = static_cast<int>(e & 0xFFFFu), jo = static_cast<int>(e >> 16);
-        const double2 pi = lds_at<double2>(smem, io), vi = lds_at<double2>(smem, io + VEL);
-        const double2 pj = lds_at<double2>(smem, jo), vj = lds_at<double2>(smem, jo + VEL);
-        R qx, qy;
-        pair_force_state<R>(k, pi.x, pi.y, vi.x, vi.y, pj.x, pj.y, vj.x, vj.y, qx, qy);
-        atomicAdd(&lds_at<double>(smem, io + FRC), static_cast<double>(qx));
-        atomicAdd(&lds_at<double>(smem, io + FRC + 8), static_cast<double>(qy));
-        // j receives -q: accumulated with the opposite sign, subtracted in the agent pass
-        atomicAdd(&lds_at<double>(smem, jo + FRJ), static_cast<double>(qx));
-        atomicAdd(&lds_at<double>(smem, jo + FRJ + 8), static_cast<double>(qy));
+    if (n_it > 0) {
+      uint32_t ia, ja, ib, jb;
+      load_pair_entries(tab_i, tab_j, lane_off, ia, ja);
+      for (int it = 0; it < n_it; it += 2) {
+        wait_pair_entries(ia, ja);  // also covers the robot record issued a step ago
+        if (it + 1 < n_it) load_pair_entries(tab_i + (it + 1) * WAVE, tab_j + (it + 1) * WAVE, lane_off, ib, jb);
+        pair_at(ia, ja);
+        if (it + 1 >= n_it) break;
+        wait_pair_entries(ib, jb);
+        if (it + 2 < n_it) load_pair_entries(tab_i + (it + 2) * WAVE, tab_j + (it + 2) * WAVE, lane_off, ia, ja);
+        pair_at(ib, jb);
       }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    const sfw_robot_step rs = L.rstep[static_cast<int64_t>(step) * L.rstep_stride + rsample];
+    // ---- per-agent pass: its parameters are read here, not held across the pair loop -----------
+    const late_launch La = late_args();
+    const agent_consts c = load_agent_consts(La, F32);
+    const sfw_agent_const *const agent_c = La->agent_c;
+    const sfw_robot_step rs = s.rsb[step & 1];
+    if (step + 1 < step_end) fetch_robot(La->rstep, La->rstep_stride, step + 1, (step + 1) & 1);
     for (int sl = lane; sl < A; sl += WAVE) {
-      const agent_k ak = GROUPS ? agent_k_lds(s, sl) : agent_k_global(L, sl);
-      const double2 Fi = s.frc[sl], Fj = s.frj[sl];
-      double2 p = s.pos[sl], v = s.vel[sl];
+      const agent_k ak = GROUPS ? agent_k_lds(s, sl) : agent_k_global(agent_c, sl);
+      double px = s.px[sl], py = s.py[sl], vx = s.vx[sl], vy = s.vy[sl];
       double nfx, nfy;
-      const double w = agent_step<R>(k, s, rs, ak, step, sl, 0, sl, O, inv_O, robot_id, p.x, p.y, v.x, v.y,
-                                     Fi.x - Fj.x, Fi.y - Fj.y, nfx, nfy);
+      const double w = agent_step<R>(k, c, s, rs, ak, step, sl, 0, sl, px, py, vx, vy, s.fcx[sl] - s.fjx[sl],
+                                     s.fcy[sl] - s.fjy[sl], nfx, nfy);
       s.swp[sl] += w;
       if (sl == 0) {  // the robot does not move by SFM: post-step record (ref :600, :604 robot-local twist)
-        p = double2{rs.x, rs.y};
-        v = double2{rs.vx, rs.vy};
+        px = rs.x;
+        py = rs.y;
+        vx = rs.vx;
+        vy = rs.vy;
       }
-      s.pos[sl] = p;
-      s.vel[sl] = v;
-      s.frc[sl] = double2{nfx, nfy};
-      s.frj[sl] = double2{0.0, 0.0};
+      s.px[sl] = px;
+      s.py[sl] = py;
+      s.vx[sl] = vx;
+      s.vy[sl] = vy;
+      s.fcx[sl] = nfx;
+      s.fcy[sl] = nfy;
+      s.fjx[sl] = 0.0;
+      s.fjy[sl] = 0.0;
     }
     __syncthreads();
     if (s.dead[0] != 0) break;
-    if constexpr (GROUPS) add_group_forces();
+    if constexpr (GROUPS) add_group_forces(c);
   }
-  if (L.phase == SFW_PHASE_PREFIX) {  // leave the class record
-    sfw_cls_agent *rec = L.out_state + first_local * A;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a prefetched robot record may still be in flight
+  const late_launch Le = late_args();
+  if (Le->phase == SFW_PHASE_PREFIX) {  // leave the class record
+    sfw_cls_agent *rec = Le->out_state + first_local * A;
     for (int sl = lane; sl < A; sl += WAVE) {
-      const double2 p = s.pos[sl], v = s.vel[sl], f = s.frc[sl];
       sfw_cls_agent c;
-      c.px = p.x; c.py = p.y; c.vx = v.x; c.vy = v.y;
-      c.fx = f.x; c.fy = f.y; c.sw = s.swp[sl];
+      c.px = s.px[sl]; c.py = s.py[sl]; c.vx = s.vx[sl]; c.vy = s.vy[sl];
+      c.fx = s.fcx[sl]; c.fy = s.fcy[sl]; c.sw = s.swp[sl];
       c.hasgoal = s.hasgoal[sl];
       c.pad = 0;
       rec[sl] = c;
     }
-    if (lane == 0) L.out_dead[first_local] = s.dead[0];
+    if (lane == 0) Le->out_dead[first_local] = s.dead[0];
     return;
   }
   double sw_acc = 0.0;
   for (int sl = lane; sl < A; sl += WAVE) sw_acc += s.swp[sl];
-  finish_wave(L, s, lane, 1, 1, A, first_local, sw_acc);
+  finish_wave(s, lane, 1, 1, first_local, sw_acc);
 }
 
 // ===========================================================================
@@ -1376,20 +1481,18 @@ void sfw_derive(sfw_launch &L) {
   const sfw_params &p = L.p;
   sfw_force_k<double> &d = L.k.d;
   d.lambda = p.sfm_lambda;
-  d.gamma2 = p.sfm_gamma * p.sfm_gamma;
   d.neg_inv_gamma = -1.0 / p.sfm_gamma;
-  d.neg_n2 = -(p.sfm_n * p.sfm_n);
-  d.neg_n_prime2 = -(p.sfm_n_prime * p.sfm_n_prime);
-  d.f_social = p.sfm_force_factor_social;
+  d.ln_f_social = std::log(p.sfm_force_factor_social);  // -inf for Fs = 0: the clamp at -800 makes the force 0
+  d.c_vel = -(p.sfm_n_prime * p.sfm_n_prime) * (p.sfm_gamma * p.sfm_gamma);
+  d.c_ang = -(p.sfm_n * p.sfm_n) * (p.sfm_gamma * p.sfm_gamma);
   d.f_obstacle = p.sfm_force_factor_obstacle;
   d.inv_sigma = 1.0 / p.sfm_force_sigma_obstacle;
   sfw_force_k<float> &f = L.k.f;
   f.lambda = static_cast<float>(d.lambda);
-  f.gamma2 = static_cast<float>(d.gamma2);
   f.neg_inv_gamma = static_cast<float>(d.neg_inv_gamma);
-  f.neg_n2 = static_cast<float>(d.neg_n2);
-  f.neg_n_prime2 = static_cast<float>(d.neg_n_prime2);
-  f.f_social = static_cast<float>(d.f_social);
+  f.ln_f_social = static_cast<float>(d.ln_f_social);
+  f.c_vel = static_cast<float>(d.c_vel);
+  f.c_ang = static_cast<float>(d.c_ang);
   f.f_obstacle = static_cast<float>(d.f_obstacle);
   f.inv_sigma = static_cast<float>(d.inv_sigma);
   L.k.f_desired = p.sfm_force_factor_desired;
@@ -1398,12 +1501,15 @@ void sfw_derive(sfw_launch &L) {
   L.k.inv_O = L.O > 0 ? 1.0 / L.O : 0.0;
 }
 
-static int flat_cap(int A) { return A <= 64 ? 64 : A <= 128 ? 128 : A <= 256 ? 256 : 0; }
+// Capacity (doubles per LDS plane) of the flat kernel for A agents: compile-time 64 / 128 / 256 when A fits with
+// one record to spare (the dummy slot of the padded pair table), otherwise 0 = run-time (A + 1 rounded up to even).
+static int flat_cap(int A) { return A < 64 ? 64 : A < 128 ? 128 : A < 256 ? 256 : 0; }
+static int flat_cap_runtime(int A) { return (A + 2) & ~1; }
 
 static size_t lds_bytes_for(const wave_plan &pl, int A, int O, int NG, int n_grp_mem) {
   if (pl.flat) {
     const int c = flat_cap(A);
-    return lds_layout(nullptr, A, c > 0 ? c : A, A, 1, O, NG, n_grp_mem, NG > 0, true).bytes;
+    return lds_layout(nullptr, A, c > 0 ? c : flat_cap_runtime(A), A, 1, O, NG, n_grp_mem, NG > 0, true).bytes;
   }
   return lds_layout(nullptr, A, WAVE * pl.ns, pl.G * A, pl.G, O, NG, n_grp_mem, true, false).bytes;
 }
@@ -1416,14 +1522,15 @@ size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T) {
   return a > b ? a : b;
 }
 
+// uint16 entries of the pair table: two arrays (i offsets, j offsets) of ceil(P / 64) * 64 entries each
 int64_t sfw_pair_table_entries(int A) {
   const int64_t P = static_cast<int64_t>(A) * (A - 1) / 2;
   const int64_t n = (P + WAVE - 1) / WAVE * WAVE;
-  return n > 0 ? n : WAVE;
+  return 2 * (n > 0 ? n : WAVE);
 }
 
-hipError_t sfw_launch_pair_table(uint32_t *tab, int A, hipStream_t stream) {
-  const int n = static_cast<int>(sfw_pair_table_entries(A));
+hipError_t sfw_launch_pair_table(uint16_t *tab, int A, hipStream_t stream) {
+  const int n = static_cast<int>(sfw_pair_table_entries(A) / 2);
   hipLaunchKernelGGL(sfw_pair_table_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tab, A, n);
   return hipGetLastError();
 }
@@ -1487,7 +1594,7 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L,
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const bool groups = L.NG > 0;  // at least one agent carries a group id: kernels with the group pass
   if (pl.flat) {
-    if (16 * static_cast<int64_t>(L.A) > 65535 || !L.pair_tab) return hipErrorInvalidValue;  // 16-bit packed offsets
+    if (8 * (static_cast<int64_t>(L.A) + 1) > 65535 || !L.pair_tab) return hipErrorInvalidValue;  // 16-bit plane offsets
     switch (flat_cap(L.A)) {
       case 64:
         return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 64>, L, 1, grid, lds, stream)

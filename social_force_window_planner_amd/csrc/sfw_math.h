@@ -43,13 +43,17 @@ __device__ __forceinline__ float vgpr_const(float c) {
   asm("" : "+v"(c));
   return c;
 }
+// A VOP3 instruction reads at most one SGPR operand, so the first Horner step fma(c_n, z, c_{n-1}) of a chain
+// with both coefficients in SGPRs costs an extra v_mov_b64 per evaluation: the leading coefficients live in VGPRs.
 struct poly_consts {
   double at[9], ex[10];
   __device__ __forceinline__ poly_consts() {
 #pragma unroll
-    for (int n = 0; n < 9; ++n) at[n] = sgpr_const(kAtanP[n]);
+    for (int n = 0; n < 8; ++n) at[n] = sgpr_const(kAtanP[n]);
+    at[8] = vgpr_const(kAtanP[8]);
 #pragma unroll
-    for (int n = 0; n < 10; ++n) ex[n] = sgpr_const(kExpP[n]);
+    for (int n = 0; n < 9; ++n) ex[n] = sgpr_const(kExpP[n]);
+    ex[9] = vgpr_const(kExpP[9]);
   }
 };
 // v_rsq_f64 / v_rcp_f64 deliver ~23 good bits; one Newton step gives ~46.

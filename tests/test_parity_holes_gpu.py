@@ -276,17 +276,18 @@ def test_cfg5_one_rank_shard_full_size(oracle_mod, hip_mod):
 # ---------------------------------------------------------------------------
 # sfw_set_params between stage and launch
 # ---------------------------------------------------------------------------
-def test_set_params_between_stage_and_launch(oracle_mod, hip_mod):
+def test_set_params_between_stage_and_launch(oracle_mod, hip_mod, monkeypatch):
     """Same step count, different dt (sim_time and sim_granularity both doubled) set AFTER the stage: the
     shared-prefix classes were derived for the old dt and must not be reused."""
     w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=72, nw=72, n_people=9, seed=61)
     scene = syn.make_scene(w)
     p1 = default_params(sim_time=1.0, sim_granularity=0.025)
     p2 = default_params(sim_time=2.0, sim_granularity=0.05)
+    monkeypatch.setenv("SFW_PREFIX", "5,11")  # two shared-prefix levels whatever the cost model would choose
     g = hip_mod.HipScorer(p1)
     g.load_scene(scene)
     g.stage(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
-    assert g.plan_info()["levels"] > 0
+    assert g.plan_info()["levels"] == 2
     g.set_params(p2)
     g.launch()
     costs, best, _ = g.fetch()
