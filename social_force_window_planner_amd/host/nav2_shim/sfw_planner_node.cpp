@@ -1,4 +1,4 @@
-// sfw_planner_node.cpp — see sfw_planner_node.hpp.  UNTESTED HERE (needs ROS 2 Foxy + nav2).
+// sfw_planner_node.cpp — see sfw_planner_node.hpp.  Type-checked against tests/nav2_stubs/, never run here (needs ROS 2 Foxy + nav2).
 // Control flow = reference src/sfw_planner_node.cpp:47-336; message <-> POD conversions only.
 #include "sfw_planner_node.hpp"
 

@@ -1,7 +1,9 @@
 // sfw_planner_node.hpp — nav2 plugin shell over the MI355X scorer.
 //
-// NOT COMPILED OR TESTED IN THIS REPOSITORY'S IMAGE (no ROS 2 / nav2 there; see
-// CMakeLists.txt: the target is only created when nav2_core is found).  It
+// NOT BUILT OR RUN IN THIS REPOSITORY'S IMAGE (no ROS 2 / nav2 there; see
+// CMakeLists.txt: the target is only created when nav2_core is found).  It is
+// type-checked on every test run against declarations of the names it uses
+// (tests/nav2_stubs/, tests/test_nav2_shim_syntax.py: g++ -fsyntax-only -Werror).  It
 // mirrors the reference class social_force_window_planner::SFWPlannerNode
 // (reference include/social_force_window_planner/sfw_planner_node.hpp:53-175,
 // src/sfw_planner_node.cpp:47-336): same class name, same base, same Foxy-era
