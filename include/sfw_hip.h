@@ -280,6 +280,47 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
  * to record their own events. */
 void *sfw_stream(sfw_handle h);
 
+/* ---- one process, several devices ---------------------------------------
+ * The reference plugin is ONE process (sfw_plugin.xml:1-9; computeVelocityCommands,
+ * src/sfw_planner_node.cpp:220-331), so a host that wants the (v,w) grid on several
+ * MI355X drives them from there: one sfw_handle per listed device, the linvel rows
+ * (the OUTER loop of src/sfw_planner.cpp:345) split into contiguous blocks
+ * [r*nv/R, (r+1)*nv/R), world state replicated by each handle's own upload, and the
+ * winner picked by ONE ncclAllReduce(min) over xGMI of an [R,5] double table in which
+ * rank r fills its own row (sfw_best_key + n_valid) and +inf elsewhere — the
+ * lexicographic row minimum is the reference's selection order (:394-414).  RCCL is
+ * loaded on first use (dlopen librccl.so): single-device callers never touch it. */
+typedef struct sfw_multi_s *sfw_multi_handle;
+#define SFW_MULTI_RCCL 0        /* devices must be distinct; exchange = ncclAllReduce(min)            */
+#define SFW_MULTI_HOST_REDUCE 1 /* exchange on the host from each rank's 40-byte row: no RCCL needed, a
+                                   device may be listed more than once (tests on a one-GPU box)       */
+int sfw_multi_create(const sfw_params *params, const int *devices, int32_t R, int32_t exchange,
+                     sfw_multi_handle *out);
+int sfw_multi_destroy(sfw_multi_handle m);
+const char *sfw_multi_last_error(sfw_multi_handle m);
+int32_t sfw_multi_ranks(sfw_multi_handle m);
+/* Rank r's handle (owned by m): for the single-sample calls (sfw_score_one on rank 0) and diagnostics. */
+sfw_handle sfw_multi_rank_handle(sfw_multi_handle m, int32_t r);
+/* World state and parameters, replicated to every rank. */
+int sfw_multi_set_params(sfw_multi_handle m, const sfw_params *params);
+int sfw_multi_set_costmap(sfw_multi_handle m, const uint8_t *cells, uint32_t size_x, uint32_t size_y,
+                          double origin_x, double origin_y, double resolution);
+int sfw_multi_set_footprint(sfw_multi_handle m, const double *xy, int32_t K);
+int sfw_multi_set_agents(sfw_multi_handle m, const sfw_agent *agents, int32_t A, const double *obstacles_xy,
+                         int32_t O);
+/* sfw_score_grid over all ranks: same arguments, same results (costs bit-identical: a sample's cost does
+ * not depend on how the grid is cut).  costs_out / best_out may be NULL. */
+int sfw_multi_score_grid(sfw_multi_handle m, const sfw_robot_state *rs, const double *linvels, int32_t nv,
+                         const double *angvels, int32_t nw, const sfw_goal_args *args, double *costs_out,
+                         sfw_best *best_out);
+/* Host wall-clock of the last call's phases, microseconds: which = 0 stage+launch of all ranks (enqueue),
+ * 1 exchange (enqueue of the all-reduce + fetch of the table, i.e. until every rank's kernels are done),
+ * 2 cost-vector fetches. */
+int sfw_multi_last_us(sfw_multi_handle m, int32_t which, double *us_out);
+/* Trajectory points of sample `index` of the last sfw_multi_score_grid (as sfw_grid_points). */
+int sfw_multi_grid_points(sfw_multi_handle m, int64_t index, double *points_xyth, int32_t points_cap,
+                          int32_t *n_points);
+
 #ifdef __cplusplus
 }
 #endif

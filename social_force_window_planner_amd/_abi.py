@@ -163,7 +163,20 @@ EXPORTED_SYMBOLS = (
     "sfw_grid_points",
     "sfw_grid_points_batch",
     "sfw_stream",
+    "sfw_multi_create",
+    "sfw_multi_destroy",
+    "sfw_multi_last_error",
+    "sfw_multi_ranks",
+    "sfw_multi_rank_handle",
+    "sfw_multi_set_params",
+    "sfw_multi_set_costmap",
+    "sfw_multi_set_footprint",
+    "sfw_multi_set_agents",
+    "sfw_multi_score_grid",
+    "sfw_multi_last_us",
+    "sfw_multi_grid_points",
 )
+SFW_MULTI_RCCL, SFW_MULTI_HOST_REDUCE = 0, 1
 
 
 class CtrlParams(C.Structure):

@@ -5,7 +5,11 @@
 
 #include "sfw_device.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1178,5 +1182,299 @@ int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth, int32_t po
 }
 
 void *sfw_stream(sfw_handle h) { return h ? static_cast<void *>(h->stream) : nullptr; }
+
+}  // extern "C"
+
+// ===========================================================================
+// one process, several devices (sfw_multi_*)
+// ===========================================================================
+namespace {
+// librccl.so, resolved on first use: a single-device caller never loads it
+struct rccl_api {
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string load() {
+    if (lib) return "";
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) return std::string("cannot load librccl.so: ") + dlerror();
+    auto sym = [&](const char *n) { return dlsym(lib, n); };
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd || !GetErrorString) {
+      dlclose(lib);
+      lib = nullptr;
+      return "librccl.so lacks ncclCommInitAll/ncclAllReduce/ncclGroupStart/...";
+    }
+    return "";
+  }
+};
+rccl_api g_rccl;
+}  // namespace
+
+struct sfw_multi_s {
+  int R = 0;
+  int exchange = SFW_MULTI_RCCL;
+  std::vector<sfw_handle> h;
+  std::vector<int> dev;
+  std::vector<ncclComm_t> comm;       // RCCL exchange only
+  std::vector<double *> d_table;      // per rank: [R,5] doubles on its device
+  double *pin_table = nullptr;        // pinned host copy: the reduced table (RCCL) or the ranks' own rows (host reduce)
+  std::vector<int32_t> row0;          // R + 1 row offsets of the last grid
+  std::vector<double> lin, ang;
+  int32_t nv = 0, nw = 0;
+  bool scored = false;
+  double us[3] = {0, 0, 0};
+  std::string err;
+};
+
+namespace {
+int mfail(sfw_multi_handle m, int code, const std::string &msg) {
+  if (m) m->err = msg;
+  return code;
+}
+int mrank_fail(sfw_multi_handle m, int r, int code, const char *what) {
+  return mfail(m, code, std::string(what) + " on rank " + std::to_string(r) + ": " + sfw_last_error(m->h[static_cast<size_t>(r)]));
+}
+double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+extern "C" {
+
+int sfw_multi_create(const sfw_params *params, const int *devices, int32_t R, int32_t exchange, sfw_multi_handle *out) {
+  if (!out) return SFW_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!params || !devices || R <= 0 || R > 64 || (exchange != SFW_MULTI_RCCL && exchange != SFW_MULTI_HOST_REDUCE))
+    return SFW_ERR_INVALID_ARG;
+  if (exchange == SFW_MULTI_RCCL)
+    for (int a = 0; a < R; ++a)
+      for (int b = a + 1; b < R; ++b)
+        if (devices[a] == devices[b]) return SFW_ERR_INVALID_ARG;  // one RCCL rank per device
+  sfw_multi_handle m = new (std::nothrow) sfw_multi_s();
+  if (!m) return SFW_ERR_HIP;
+  m->R = R;
+  m->exchange = exchange;
+  m->dev.assign(devices, devices + R);
+  m->d_table.assign(static_cast<size_t>(R), nullptr);
+  int rc = SFW_OK;
+  for (int r = 0; r < R && rc == SFW_OK; ++r) {
+    sfw_handle h = nullptr;
+    rc = sfw_create(params, devices[r], &h);
+    if (rc == SFW_OK) {
+      m->h.push_back(h);
+      if (hipSetDevice(devices[r]) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void **>(&m->d_table[static_cast<size_t>(r)]), sizeof(double) * 5 * R) != hipSuccess)
+        rc = SFW_ERR_HIP;
+    }
+  }
+  if (rc == SFW_OK && hipHostMalloc(reinterpret_cast<void **>(&m->pin_table), sizeof(double) * 5 * R, hipHostMallocDefault) != hipSuccess)
+    rc = SFW_ERR_HIP;
+  if (rc == SFW_OK && exchange == SFW_MULTI_RCCL) {
+    const std::string e = g_rccl.load();
+    if (!e.empty()) rc = SFW_ERR_UNSUPPORTED;
+    else {
+      m->comm.assign(static_cast<size_t>(R), nullptr);
+      const ncclResult_t nr = g_rccl.CommInitAll(m->comm.data(), R, devices);
+      if (nr != ncclSuccess) {
+        m->comm.clear();
+        rc = SFW_ERR_HIP;
+      }
+    }
+  }
+  if (rc != SFW_OK) {
+    sfw_multi_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return SFW_OK;
+}
+
+int sfw_multi_destroy(sfw_multi_handle m) {
+  if (!m) return SFW_OK;
+  for (size_t r = 0; r < m->h.size(); ++r) (void)sfw_grid_sync(m->h[r]);
+  for (ncclComm_t c : m->comm)
+    if (c) (void)g_rccl.CommDestroy(c);
+  for (size_t r = 0; r < m->d_table.size(); ++r)
+    if (m->d_table[r]) {
+      (void)hipSetDevice(m->dev[r]);
+      (void)hipFree(m->d_table[r]);
+    }
+  if (m->pin_table) (void)hipHostFree(m->pin_table);
+  for (sfw_handle h : m->h) (void)sfw_destroy(h);
+  delete m;
+  return SFW_OK;
+}
+
+const char *sfw_multi_last_error(sfw_multi_handle m) { return m ? m->err.c_str() : "null handle"; }
+int32_t sfw_multi_ranks(sfw_multi_handle m) { return m ? m->R : 0; }
+sfw_handle sfw_multi_rank_handle(sfw_multi_handle m, int32_t r) {
+  return (m && r >= 0 && r < m->R) ? m->h[static_cast<size_t>(r)] : nullptr;
+}
+
+int sfw_multi_set_params(sfw_multi_handle m, const sfw_params *params) {
+  if (!m) return SFW_ERR_INVALID_ARG;
+  for (int r = 0; r < m->R; ++r)
+    if (int e = sfw_set_params(m->h[static_cast<size_t>(r)], params)) return mrank_fail(m, r, e, "sfw_set_params");
+  return SFW_OK;
+}
+int sfw_multi_set_costmap(sfw_multi_handle m, const uint8_t *cells, uint32_t size_x, uint32_t size_y, double origin_x,
+                          double origin_y, double resolution) {
+  if (!m) return SFW_ERR_INVALID_ARG;
+  for (int r = 0; r < m->R; ++r)
+    if (int e = sfw_set_costmap(m->h[static_cast<size_t>(r)], cells, size_x, size_y, origin_x, origin_y, resolution))
+      return mrank_fail(m, r, e, "sfw_set_costmap");
+  return SFW_OK;
+}
+int sfw_multi_set_footprint(sfw_multi_handle m, const double *xy, int32_t K) {
+  if (!m) return SFW_ERR_INVALID_ARG;
+  for (int r = 0; r < m->R; ++r)
+    if (int e = sfw_set_footprint(m->h[static_cast<size_t>(r)], xy, K)) return mrank_fail(m, r, e, "sfw_set_footprint");
+  return SFW_OK;
+}
+int sfw_multi_set_agents(sfw_multi_handle m, const sfw_agent *agents, int32_t A, const double *obstacles_xy, int32_t O) {
+  if (!m) return SFW_ERR_INVALID_ARG;
+  for (int r = 0; r < m->R; ++r)
+    if (int e = sfw_set_agents(m->h[static_cast<size_t>(r)], agents, A, obstacles_xy, O)) return mrank_fail(m, r, e, "sfw_set_agents");
+  return SFW_OK;
+}
+
+int sfw_multi_score_grid(sfw_multi_handle m, const sfw_robot_state *rs, const double *linvels, int32_t nv,
+                         const double *angvels, int32_t nw, const sfw_goal_args *args, double *costs_out,
+                         sfw_best *best_out) {
+  if (!m) return SFW_ERR_INVALID_ARG;
+  if (!rs || !linvels || !angvels || !args || nv <= 0 || nw <= 0)
+    return mfail(m, SFW_ERR_INVALID_ARG, "multi_score_grid: null pointer or non-positive sample count");
+  const int R = m->R;
+  m->scored = false;
+  m->lin.assign(linvels, linvels + nv);
+  m->ang.assign(angvels, angvels + nw);
+  m->nv = nv;
+  m->nw = nw;
+  m->row0.assign(static_cast<size_t>(R) + 1, 0);
+  for (int r = 0; r <= R; ++r) m->row0[static_cast<size_t>(r)] = static_cast<int32_t>((static_cast<int64_t>(r) * nv) / R);  // ref :345: rows are the outer axis
+  const double t0 = now_us();
+  // (1) every rank: stage its block of rows, enqueue the kernels and its row of the exchange table
+  for (int r = 0; r < R; ++r) {
+    sfw_handle h = m->h[static_cast<size_t>(r)];
+    const int32_t lo = m->row0[static_cast<size_t>(r)], n = m->row0[static_cast<size_t>(r) + 1] - lo;
+    SFW_HIP(h, hipSetDevice(m->dev[static_cast<size_t>(r)]));
+    if (n > 0) {
+      if (int e = sfw_grid_stage(h, rs, linvels + lo, n, angvels, nw, args, static_cast<int64_t>(lo) * nw))
+        return mrank_fail(m, r, e, "sfw_grid_stage");
+      if (int e = sfw_grid_launch(h)) return mrank_fail(m, r, e, "sfw_grid_launch");
+      if (sfw_launch_key_table(h->d_sel, m->d_table[static_cast<size_t>(r)], r, R, h->stream) != hipSuccess)
+        return mfail(m, SFW_ERR_HIP, "key table launch failed");
+    } else {  // fewer rows than ranks: this rank holds nothing, its row stays +inf / 0 valid
+      for (int e = 0; e < 5 * R; ++e) m->pin_table[e] = std::numeric_limits<double>::infinity();
+      m->pin_table[5 * r + 4] = 0.0;
+      if (hipMemcpyAsync(m->d_table[static_cast<size_t>(r)], m->pin_table, sizeof(double) * 5 * R, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+          hipStreamSynchronize(h->stream) != hipSuccess)
+        return mfail(m, SFW_ERR_HIP, "empty-rank table upload failed");
+    }
+  }
+  const double t1 = now_us();
+  // (2) the exchange
+  if (m->exchange == SFW_MULTI_RCCL) {
+    ncclResult_t nr = g_rccl.GroupStart();
+    for (int r = 0; r < R && nr == ncclSuccess; ++r) {
+      (void)hipSetDevice(m->dev[static_cast<size_t>(r)]);
+      double *t = m->d_table[static_cast<size_t>(r)];
+      nr = g_rccl.AllReduce(t, t, static_cast<size_t>(5) * R, ncclDouble, ncclMin, m->comm[static_cast<size_t>(r)],
+                            m->h[static_cast<size_t>(r)]->stream);
+    }
+    const ncclResult_t ne = g_rccl.GroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return mfail(m, SFW_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nr));
+    sfw_handle h0 = m->h[0];
+    SFW_HIP(h0, hipSetDevice(m->dev[0]));
+    SFW_HIP(h0, hipMemcpyAsync(m->pin_table, m->d_table[0], sizeof(double) * 5 * R, hipMemcpyDeviceToHost, h0->stream));
+    SFW_HIP(h0, hipStreamSynchronize(h0->stream));
+  } else {  // host reduce: each rank's own row
+    for (int r = 0; r < R; ++r) {
+      sfw_handle h = m->h[static_cast<size_t>(r)];
+      SFW_HIP(h, hipSetDevice(m->dev[static_cast<size_t>(r)]));
+      SFW_HIP(h, hipMemcpyAsync(m->pin_table + 5 * r, m->d_table[static_cast<size_t>(r)] + 5 * r, sizeof(double) * 5,
+                                hipMemcpyDeviceToHost, h->stream));
+    }
+    for (int r = 0; r < R; ++r) {
+      sfw_handle h = m->h[static_cast<size_t>(r)];
+      SFW_HIP(h, hipSetDevice(m->dev[static_cast<size_t>(r)]));
+      SFW_HIP(h, hipStreamSynchronize(h->stream));
+    }
+  }
+  const double t2 = now_us();
+  // (3) cost slices
+  if (costs_out)
+    for (int r = 0; r < R; ++r) {
+      const int32_t lo = m->row0[static_cast<size_t>(r)], n = m->row0[static_cast<size_t>(r) + 1] - lo;
+      if (n > 0)
+        if (int e = sfw_grid_fetch(m->h[static_cast<size_t>(r)], costs_out + static_cast<int64_t>(lo) * nw, nullptr, nullptr))
+          return mrank_fail(m, r, e, "sfw_grid_fetch");
+    }
+  const double t3 = now_us();
+  m->us[0] = t1 - t0;
+  m->us[1] = t2 - t1;
+  m->us[2] = t3 - t2;
+  // (4) lexicographic minimum over the rows = the reference's selection order
+  if (best_out) {
+    int win = -1;
+    int64_t n_valid = 0;
+    for (int r = 0; r < R; ++r) {
+      const double *k = m->pin_table + 5 * r;
+      n_valid += static_cast<int64_t>(k[4]);
+      if (!std::isfinite(k[0])) continue;
+      if (win < 0 || std::lexicographical_compare(k, k + 4, m->pin_table + 5 * win, m->pin_table + 5 * win + 4)) win = r;
+    }
+    best_out->n_valid = n_valid;
+    if (win >= 0) {
+      const double *k = m->pin_table + 5 * win;
+      const int64_t idx = static_cast<int64_t>(-k[3]);
+      best_out->index = idx;
+      best_out->cost = k[0];
+      best_out->vx = linvels[idx / nw];
+      best_out->vy = 0.0;
+      best_out->vtheta = angvels[idx % nw];
+    } else {  // ref :456-468
+      best_out->index = -1;
+      best_out->cost = -1.0;
+      best_out->vx = best_out->vy = best_out->vtheta = 0.0;
+    }
+  }
+  m->scored = true;
+  return SFW_OK;
+}
+
+int sfw_multi_last_us(sfw_multi_handle m, int32_t which, double *us_out) {
+  if (!m || !us_out || which < 0 || which > 2) return SFW_ERR_INVALID_ARG;
+  if (!m->scored) return mfail(m, SFW_ERR_STATE, "multi_last_us before multi_score_grid");
+  *us_out = m->us[which];
+  return SFW_OK;
+}
+
+int sfw_multi_grid_points(sfw_multi_handle m, int64_t index, double *points_xyth, int32_t points_cap, int32_t *n_points) {
+  if (!m) return SFW_ERR_INVALID_ARG;
+  if (!m->scored) return mfail(m, SFW_ERR_STATE, "multi_grid_points before multi_score_grid");
+  if (index < 0 || index >= static_cast<int64_t>(m->nv) * m->nw) return mfail(m, SFW_ERR_INVALID_ARG, "multi_grid_points: bad index");
+  const int32_t row = static_cast<int32_t>(index / m->nw);
+  int r = 0;
+  while (r + 1 < m->R && row >= m->row0[static_cast<size_t>(r) + 1]) ++r;
+  const int64_t local = index - static_cast<int64_t>(m->row0[static_cast<size_t>(r)]) * m->nw;
+  if (int e = sfw_grid_points(m->h[static_cast<size_t>(r)], local, points_xyth, points_cap, n_points))
+    return mrank_fail(m, r, e, "sfw_grid_points");
+  return SFW_OK;
+}
 
 }  // extern "C"

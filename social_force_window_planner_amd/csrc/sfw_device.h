@@ -159,6 +159,8 @@ int64_t sfw_argmin_partials(int64_t T);
 hipError_t sfw_launch_argmin(const double *costs, const double *linvels, const double *angvels,
                              int32_t nw, int64_t T, int64_t index_base, sfw_sel *partials,
                              sfw_sel *out, hipStream_t stream);
+// Row r of the [R,5] multi-device exchange table from a selection record (+inf in every other row).
+hipError_t sfw_launch_key_table(const sfw_sel *sel, double *table, int r, int R, hipStream_t stream);
 // Pair table of the flat social kernel for A agents: sfw_pair_table_entries(A) uint16 entries.
 int64_t sfw_pair_table_entries(int A);
 hipError_t sfw_launch_pair_table(uint16_t *tab, int A, hipStream_t stream);

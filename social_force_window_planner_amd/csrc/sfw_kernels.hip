@@ -1435,6 +1435,22 @@ sfw_argmin_stage2(const sfw_sel *partials, int n, sfw_sel *out) {
   if (threadIdx.x == 0) *out = best;
 }
 
+// Multi-device exchange record (sfw_multi_*): row `r` of an [R,5] table = this rank's selection key
+// (cost, -linvel, |angvel|, -index) and its count of valid samples; every other row +inf, so that an
+// element-wise all-reduce(min) over the ranks assembles the table of all local keys.
+__global__ void __launch_bounds__(64) sfw_key_table_kernel(const sfw_sel *sel, double *table, int r, int R) {
+  for (int e = threadIdx.x; e < 5 * R; e += blockDim.x) {
+    double v = INFINITY;
+    if (e / 5 == r) {
+      const sfw_sel s = *sel;
+      const int c = e % 5;
+      if (c == 4) v = static_cast<double>(s.n_valid);
+      else if (isfinite(s.cost)) v = c == 0 ? s.cost : c == 1 ? s.neg_linvel : c == 2 ? s.abs_angvel : static_cast<double>(s.neg_index);
+    }
+    table[e] = v;
+  }
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -1622,6 +1638,11 @@ hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream) {
   if (L.chunk_count <= 0 || L.A <= 0) return hipSuccess;
   if (L.p.precision == SFW_PRECISION_F32) return launch_social_typed<float>(L, stream);
   return launch_social_typed<double>(L, stream);
+}
+
+hipError_t sfw_launch_key_table(const sfw_sel *sel, double *table, int r, int R, hipStream_t stream) {
+  hipLaunchKernelGGL(sfw_key_table_kernel, dim3(1), dim3(64), 0, stream, sel, table, r, R);
+  return hipGetLastError();
 }
 
 int64_t sfw_argmin_partials(int64_t T) {

@@ -42,6 +42,8 @@ def lib():
         L.sfwh_set_costmap.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]
         L.sfwh_set_agents.argtypes = [vp, vp, C.c_int32, vp, C.c_int32]
         L.sfwh_set_sample_sets.argtypes = [vp, vp, C.c_int32, vp, C.c_int32]
+        L.sfwh_set_devices.argtypes = [vp, vp, C.c_int32, C.c_int32]
+        L.sfwh_ranks.argtypes = [vp]
         L.sfwh_update_plan.argtypes = [vp, vp, C.c_int32]
         L.sfwh_find_best_action.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.sfwh_is_goal_reached.argtypes = [vp]
@@ -104,6 +106,14 @@ class HostPlanner:
         cells = np.ascontiguousarray(cells, dtype=np.uint8)
         sy, sx = cells.shape
         lib().sfwh_set_costmap(self._h, cells.ctypes.data, sx, sy, ox, oy, res)
+
+    def set_devices(self, devices, host_reduce=False):
+        """SFWPlanner::setDevices: grid rows over several devices from this process (before the first scoring call)."""
+        d = (C.c_int * len(devices))(*devices)
+        self._check(lib().sfwh_set_devices(self._h, d, len(devices), 1 if host_reduce else 0), "setDevices")
+
+    def ranks(self):
+        return lib().sfwh_ranks(self._h)
 
     def set_sample_sets(self, lin, ang):
         lin = np.ascontiguousarray(lin, dtype=np.float64)

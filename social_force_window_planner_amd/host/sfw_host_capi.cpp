@@ -118,6 +118,18 @@ int sfwh_set_agents(void *hv, const sfw_agent *agents, int32_t A, const double *
   h->agents->set.obstacles_xy.assign(obs_xy, obs_xy + 2 * static_cast<size_t>(O));
   return 0;
 }
+// Multi-device mode (SFWPlanner::setDevices); before the first scoring call.
+int sfwh_set_devices(void *hv, const int *devices, int32_t n, int32_t host_reduce) {
+  HostHandle *h = static_cast<HostHandle *>(hv);
+  try {
+    h->planner->setDevices(std::vector<int>(devices, devices + n), host_reduce != 0);
+  } catch (const std::exception &e) {
+    h->err = e.what();
+    return -1;
+  }
+  return 0;
+}
+int sfwh_ranks(void *hv) { return static_cast<HostHandle *>(hv)->planner->ranks(); }
 int sfwh_set_sample_sets(void *hv, const double *lin, int32_t nv, const double *ang, int32_t nw) {
   HostHandle *h = static_cast<HostHandle *>(hv);
   h->planner->setSampleSets(std::vector<double>(lin, lin + nv), std::vector<double>(ang, ang + nw));

@@ -98,6 +98,16 @@ SFWPlanner::SFWPlanner(const ControllerParams &params, std::shared_ptr<AgentSour
 void SFWPlanner::ensureDevice() {
   if (handle_) return;
   const sfw_params abi = params_.toAbi();
+  if (!devices_.empty()) {
+    const int rc = sfw_multi_create(&abi, devices_.data(), static_cast<int32_t>(devices_.size()),
+                                    host_reduce_ ? SFW_MULTI_HOST_REDUCE : SFW_MULTI_RCCL, &multi_);
+    if (rc != SFW_OK) {
+      multi_ = nullptr;
+      raise("sfw_multi_create (devices not visible, listed twice without host_reduce, or librccl.so missing)", rc);
+    }
+    handle_ = sfw_multi_rank_handle(multi_, 0);
+    return;
+  }
   const int rc = sfw_create(&abi, device_, &handle_);
   if (rc != SFW_OK) {
     handle_ = nullptr;
@@ -105,13 +115,21 @@ void SFWPlanner::ensureDevice() {
   }
 }
 
+void SFWPlanner::setDevices(std::vector<int> devices, bool host_reduce) {
+  if (handle_) throw std::runtime_error("SFWPlanner::setDevices: the device handle already exists");
+  devices_ = std::move(devices);
+  host_reduce_ = host_reduce;
+}
+
 SFWPlanner::~SFWPlanner() {
-  if (handle_) sfw_destroy(handle_);
+  if (multi_) sfw_multi_destroy(multi_);
+  else if (handle_) sfw_destroy(handle_);
 }
 
 void SFWPlanner::raise(const char *what, int status) const {
   std::string msg = std::string("SFWPlanner: ") + what + " failed with status " + std::to_string(status);
-  if (handle_) msg += std::string(": ") + sfw_last_error(handle_);
+  if (multi_ && *sfw_multi_last_error(multi_)) msg += std::string(": ") + sfw_multi_last_error(multi_);
+  else if (handle_) msg += std::string(": ") + sfw_last_error(handle_);
   throw std::runtime_error(msg);
 }
 
@@ -128,21 +146,31 @@ void SFWPlanner::setSampleSets(std::vector<double> lin, std::vector<double> ang)
 void SFWPlanner::uploadWorld(const AgentSet &agents) {
   ensureDevice();
   const sfw_params abi = params_.toAbi();
-  int rc = sfw_set_params(handle_, &abi);
-  if (rc != SFW_OK) raise("sfw_set_params", rc);
-  rc = sfw_set_costmap(handle_, costmap_.cells, costmap_.size_x, costmap_.size_y, costmap_.origin_x,
-                       costmap_.origin_y, costmap_.resolution);
-  if (rc != SFW_OK) raise("sfw_set_costmap", rc);
   std::vector<double> fp;
   fp.reserve(2 * footprint_spec_.size());
   for (const Point &q : footprint_spec_) { fp.push_back(q.x); fp.push_back(q.y); }
-  rc = sfw_set_footprint(handle_, fp.empty() ? nullptr : fp.data(), static_cast<int32_t>(footprint_spec_.size()));
-  if (rc != SFW_OK) raise("sfw_set_footprint", rc);
-  rc = sfw_set_agents(handle_, agents.agents.empty() ? nullptr : agents.agents.data(),
-                      static_cast<int32_t>(agents.agents.size()),
-                      agents.obstacles_xy.empty() ? nullptr : agents.obstacles_xy.data(),
-                      static_cast<int32_t>(agents.obstacles_xy.size() / 2));
-  if (rc != SFW_OK) raise("sfw_set_agents", rc);
+  const double *fpp = fp.empty() ? nullptr : fp.data();
+  const int32_t K = static_cast<int32_t>(footprint_spec_.size());
+  const sfw_agent *ag = agents.agents.empty() ? nullptr : agents.agents.data();
+  const int32_t A = static_cast<int32_t>(agents.agents.size());
+  const double *obs = agents.obstacles_xy.empty() ? nullptr : agents.obstacles_xy.data();
+  const int32_t O = static_cast<int32_t>(agents.obstacles_xy.size() / 2);
+  int rc;
+  if (multi_) {  // replicated to every rank
+    if ((rc = sfw_multi_set_params(multi_, &abi)) != SFW_OK) raise("sfw_multi_set_params", rc);
+    if ((rc = sfw_multi_set_costmap(multi_, costmap_.cells, costmap_.size_x, costmap_.size_y, costmap_.origin_x,
+                                    costmap_.origin_y, costmap_.resolution)) != SFW_OK)
+      raise("sfw_multi_set_costmap", rc);
+    if ((rc = sfw_multi_set_footprint(multi_, fpp, K)) != SFW_OK) raise("sfw_multi_set_footprint", rc);
+    if ((rc = sfw_multi_set_agents(multi_, ag, A, obs, O)) != SFW_OK) raise("sfw_multi_set_agents", rc);
+    return;
+  }
+  if ((rc = sfw_set_params(handle_, &abi)) != SFW_OK) raise("sfw_set_params", rc);
+  if ((rc = sfw_set_costmap(handle_, costmap_.cells, costmap_.size_x, costmap_.size_y, costmap_.origin_x,
+                            costmap_.origin_y, costmap_.resolution)) != SFW_OK)
+    raise("sfw_set_costmap", rc);
+  if ((rc = sfw_set_footprint(handle_, fpp, K)) != SFW_OK) raise("sfw_set_footprint", rc);
+  if ((rc = sfw_set_agents(handle_, ag, A, obs, O)) != SFW_OK) raise("sfw_set_agents", rc);
 }
 
 double SFWPlanner::scoreTrajectory(double x, double y, double theta, double vx, double vy, double vtheta,
@@ -271,10 +299,12 @@ bool SFWPlanner::findBestAction(const PoseStamped &global_pose, const Twist &glo
   const sfw_robot_state rs{rx, ry, rt, rvx, rvy, rvt};
   const sfw_goal_args ga{params_.max_trans_acc_, 0.0, params_.max_rot_acc_, wpx, wpy};
   last_costs_.assign(linvels_.size() * angvels_.size(), SFW_COST_INVALID);
-  const int rc = sfw_score_grid(handle_, &rs, linvels_.data(), static_cast<int32_t>(linvels_.size()),
-                                angvels_.data(), static_cast<int32_t>(angvels_.size()), &ga, last_costs_.data(),
-                                &last_best_);
-  if (rc != SFW_OK) raise("sfw_score_grid", rc);
+  const int32_t nv = static_cast<int32_t>(linvels_.size()), nw = static_cast<int32_t>(angvels_.size());
+  const int rc = multi_ ? sfw_multi_score_grid(multi_, &rs, linvels_.data(), nv, angvels_.data(), nw, &ga,
+                                               last_costs_.data(), &last_best_)
+                        : sfw_score_grid(handle_, &rs, linvels_.data(), nv, angvels_.data(), nw, &ga, last_costs_.data(),
+                                         &last_best_);
+  if (rc != SFW_OK) raise(multi_ ? "sfw_multi_score_grid" : "sfw_score_grid", rc);
   grid_staged_ = true;
   if (last_best_.index >= 0) {  // ref :426-455
     last_branch_ = kGrid;
@@ -292,7 +322,9 @@ bool SFWPlanner::getTrajectoryPoints(int64_t index, Trajectory &out) {
   if (S == 0) S = 1;
   std::vector<double> pts(static_cast<size_t>(3) * S);
   int32_t n = 0;
-  if (sfw_grid_points(handle_, index, pts.data(), S, &n) != SFW_OK) return false;
+  if ((multi_ ? sfw_multi_grid_points(multi_, index, pts.data(), S, &n) : sfw_grid_points(handle_, index, pts.data(), S, &n)) !=
+      SFW_OK)
+    return false;
   out.resetPoints();
   const int64_t nw = static_cast<int64_t>(angvels_.size());
   out.xv_ = linvels_[static_cast<size_t>(index / nw)];
@@ -311,7 +343,17 @@ bool SFWPlanner::getTrajectories(std::vector<Trajectory> &out) {
   const int64_t T = static_cast<int64_t>(linvels_.size()) * nw;
   std::vector<double> pts(static_cast<size_t>(3) * S * T);
   std::vector<int32_t> n(static_cast<size_t>(T));
-  if (sfw_grid_points_batch(handle_, 0, T, pts.data(), n.data()) != SFW_OK) return false;
+  if (multi_) {  // every rank dumps its own block of rows
+    const int64_t nv = static_cast<int64_t>(linvels_.size()), R = sfw_multi_ranks(multi_);
+    for (int64_t r = 0; r < R; ++r) {
+      const int64_t lo = r * nv / R * nw, cnt = (r + 1) * nv / R * nw - lo;
+      if (cnt > 0 && sfw_grid_points_batch(sfw_multi_rank_handle(multi_, static_cast<int32_t>(r)), 0, cnt,
+                                           pts.data() + static_cast<size_t>(lo) * 3 * S, n.data() + lo) != SFW_OK)
+        return false;
+    }
+  } else if (sfw_grid_points_batch(handle_, 0, T, pts.data(), n.data()) != SFW_OK) {
+    return false;
+  }
   out.assign(static_cast<size_t>(T), Trajectory());
   for (int64_t i = 0; i < T; ++i) {
     Trajectory &t = out[static_cast<size_t>(i)];

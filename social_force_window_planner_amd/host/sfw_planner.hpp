@@ -120,6 +120,13 @@ class SFWPlanner {
   void setParams(const ControllerParams &p);
   const ControllerParams &params() const { return params_; }
   void setCostmap(const CostmapView &c) { costmap_ = c; }
+  // Score the grid on several devices from this one process (the reference plugin is one process,
+  // sfw_plugin.xml:1-9): rows of the grid split over the listed devices, one RCCL all-reduce(min) picks
+  // the command (include/sfw_hip.h: sfw_multi_*).  Call before the first scoring call.  host_reduce: exchange
+  // on the host instead of RCCL, which lets a device be listed more than once (tests on a one-GPU box).
+  // The two single-sample branches (:204-206, :299-301) run on the first listed device.
+  void setDevices(std::vector<int> devices, bool host_reduce = false);
+  int ranks() const { return multi_ ? sfw_multi_ranks(multi_) : 1; }
   // Replace the sample sets (BASELINE.json grids); default = reference 5 x 9.
   void setSampleSets(std::vector<double> linvels, std::vector<double> angvels);
   const std::vector<double> &linvels() const { return linvels_; }
@@ -156,7 +163,10 @@ class SFWPlanner {
   std::vector<Point> footprint_spec_;
   std::vector<PoseStamped> global_plan_;
   std::vector<double> linvels_, angvels_;
-  sfw_handle handle_ = nullptr;
+  sfw_handle handle_ = nullptr;      // single device; with multi_: rank 0's handle (owned by multi_)
+  sfw_multi_handle multi_ = nullptr;
+  std::vector<int> devices_;         // non-empty: multi-device mode
+  bool host_reduce_ = false;
   int device_ = 0;
   std::vector<double> last_costs_;
   sfw_best last_best_{};

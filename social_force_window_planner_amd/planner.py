@@ -90,6 +90,22 @@ def lib():
         L.sfw_grid_points_batch.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
         L.sfw_stream.argtypes = [vp]
         L.sfw_stream.restype = vp
+        L.sfw_multi_create.argtypes = [C.POINTER(SfwParams), C.POINTER(C.c_int), C.c_int32, C.c_int32, C.POINTER(vp)]
+        L.sfw_multi_destroy.argtypes = [vp]
+        L.sfw_multi_last_error.argtypes = [vp]
+        L.sfw_multi_last_error.restype = C.c_char_p
+        L.sfw_multi_ranks.argtypes = [vp]
+        L.sfw_multi_ranks.restype = C.c_int32
+        L.sfw_multi_rank_handle.argtypes = [vp, C.c_int32]
+        L.sfw_multi_rank_handle.restype = vp
+        L.sfw_multi_set_params.argtypes = [vp, C.POINTER(SfwParams)]
+        L.sfw_multi_set_costmap.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]
+        L.sfw_multi_set_footprint.argtypes = [vp, vp, C.c_int32]
+        L.sfw_multi_set_agents.argtypes = [vp, vp, C.c_int32, vp, C.c_int32]
+        L.sfw_multi_score_grid.argtypes = [vp, C.POINTER(SfwRobotState), vp, C.c_int32, vp, C.c_int32,
+                                           C.POINTER(SfwGoalArgs), vp, C.POINTER(SfwBest)]
+        L.sfw_multi_last_us.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
+        L.sfw_multi_grid_points.argtypes = [vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 
@@ -232,4 +248,76 @@ class HipScorer:
         n = C.c_int32()
         self._check(lib().sfw_grid_points(self._h, index, pts.ctypes.data, points_cap, C.byref(n)),
                     "sfw_grid_points")
+        return pts[: min(n.value, points_cap)].copy()
+
+
+class MultiScorer:
+    """sfw_multi_*: one process driving one handle per listed device (rows of the grid split over them, one
+    RCCL all-reduce(min) of the [R,5] key table).  exchange = SFW_MULTI_HOST_REDUCE lets a device be listed
+    more than once (tests on a one-GPU box)."""
+
+    def __init__(self, params=None, devices=(0,), exchange=0):
+        self.params = params if params is not None else default_params()
+        self._m = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = lib().sfw_multi_create(C.byref(self.params), devs, len(devices), exchange, C.byref(self._m))
+        if rc != SFW_OK:
+            raise SfwError(rc, "sfw_multi_create")
+        self.n_ranks = lib().sfw_multi_ranks(self._m)
+
+    def close(self):
+        if getattr(self, "_m", None):
+            lib().sfw_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != SFW_OK:
+            raise SfwError(rc, what, (lib().sfw_multi_last_error(self._m) or b"").decode())
+
+    def load_scene(self, scene):
+        cells = np.ascontiguousarray(scene.cells, dtype=np.uint8)
+        sy, sx = cells.shape
+        self._check(lib().sfw_multi_set_costmap(self._m, cells.ctypes.data, sx, sy, scene.origin_x, scene.origin_y,
+                                                scene.resolution), "sfw_multi_set_costmap")
+        xy = _f64(scene.footprint).reshape(-1, 2)
+        self._check(lib().sfw_multi_set_footprint(self._m, xy.ctypes.data if len(xy) else None, len(xy)),
+                    "sfw_multi_set_footprint")
+        obs = _f64(scene.obstacles if scene.obstacles is not None else np.zeros((0, 2))).reshape(-1, 2)
+        n = len(scene.agents)
+        self._check(lib().sfw_multi_set_agents(self._m, C.addressof(scene.agents) if n else None, n,
+                                               obs.ctypes.data if len(obs) else None, len(obs)), "sfw_multi_set_agents")
+
+    def set_params(self, params):
+        self._check(lib().sfw_multi_set_params(self._m, C.byref(params)), "sfw_multi_set_params")
+        self.params = params
+
+    def score_grid(self, robot_state, linvels, angvels, goal_args, want_costs=True):
+        lin, ang = _f64(linvels), _f64(angvels)
+        rs, ga = SfwRobotState(*robot_state), SfwGoalArgs(*goal_args)
+        costs = np.empty(len(lin) * len(ang), dtype=np.float64) if want_costs else None
+        best = SfwBest()
+        self._check(lib().sfw_multi_score_grid(self._m, C.byref(rs), lin.ctypes.data, len(lin), ang.ctypes.data,
+                                               len(ang), C.byref(ga), costs.ctypes.data if want_costs else None,
+                                               C.byref(best)), "sfw_multi_score_grid")
+        return costs, best.as_dict()
+
+    def last_us(self):
+        out = []
+        for which in range(3):
+            v = C.c_double()
+            self._check(lib().sfw_multi_last_us(self._m, which, C.byref(v)), "sfw_multi_last_us")
+            out.append(v.value)
+        return {"enqueue_us": out[0], "exchange_us": out[1], "fetch_us": out[2]}
+
+    def grid_points(self, index, points_cap=4096):
+        pts = np.zeros((points_cap, 3), dtype=np.float64)
+        n = C.c_int32()
+        self._check(lib().sfw_multi_grid_points(self._m, index, pts.ctypes.data, points_cap, C.byref(n)),
+                    "sfw_multi_grid_points")
         return pts[: min(n.value, points_cap)].copy()

@@ -1,0 +1,127 @@
+"""Single-process multi-device entry of the C ABI (include/sfw_hip.h: sfw_multi_*) and its use by the C++ host
+mirror (SFWPlanner::setDevices).  On the one-GPU box: R = 1 over RCCL (ncclCommInitAll + ncclAllReduce(min) really
+run) and R = 2, 3 on handles sharing the device behind the host-side reduce, all bit-equal to sfw_score_grid."""
+import dataclasses
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from social_force_window_planner_amd import synthetic as syn
+from social_force_window_planner_amd._abi import SFW_MULTI_HOST_REDUCE, SFW_MULTI_RCCL, default_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scene(nv, nw, n_people=9, seed=71, **kw):
+    return syn.make_scene(dataclasses.replace(syn.WORKLOADS["cfg2"], nv=nv, nw=nw, n_people=n_people, seed=seed, **kw))
+
+
+@pytest.mark.parametrize("devices,exchange", [((0,), SFW_MULTI_RCCL), ((0, 0), SFW_MULTI_HOST_REDUCE),
+                                              ((0, 0, 0), SFW_MULTI_HOST_REDUCE)])
+@pytest.mark.parametrize("nv,nw", [(24, 16), (72, 72), (2, 9)])
+def test_multi_equals_single(hip_mod, devices, exchange, nv, nw):
+    scene = _scene(nv, nw)
+    p = default_params()
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    c1, b1 = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    m = hip_mod.MultiScorer(p, devices=devices, exchange=exchange)
+    assert m.n_ranks == len(devices)
+    m.load_scene(scene)
+    c2, b2 = m.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert np.array_equal(c1, c2) and b1 == b2
+    # without the cost vector: the selection alone, from the exchanged table
+    _, b3 = m.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args, want_costs=False)
+    assert b3 == b1
+    us = m.last_us()
+    assert us["exchange_us"] > 0 and us["enqueue_us"] > 0
+    # Trajectory points route to the rank that holds the sample
+    for idx in (1, nv * nw - 1, (nv // 2) * nw + 3):
+        assert np.array_equal(m.grid_points(idx), g.grid_points(idx))
+
+
+def test_multi_tie_across_ranks_and_all_invalid(hip_mod):
+    """A full tie between samples of different ranks must resolve as in one launch (later iterate wins), and a
+    grid without a selectable sample returns index -1 with the summed n_valid."""
+    scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["cfg1"], nv=8, nw=9, footprint="point", map_size=400))
+    p = default_params(sim_time=0.5, distance_weight=0.0, angle_weight=0.0)  # cost depends on the row only
+    lin = np.array([0.1, 0.3, 0.3, 0.5, 0.5, 0.5, 0.2, 0.5])  # equal target speeds in different ranks' blocks
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    c1, b1 = g.score_grid(scene.robot_state, lin, scene.angvels, scene.goal_args)
+    m = hip_mod.MultiScorer(p, devices=(0, 0, 0), exchange=SFW_MULTI_HOST_REDUCE)
+    m.load_scene(scene)
+    c2, b2 = m.score_grid(scene.robot_state, lin, scene.angvels, scene.goal_args)
+    assert np.array_equal(c1, c2) and b1 == b2
+    assert (c1 == c1[b1["index"]]).sum() > 9  # the winner's cost occurs in several rows
+    scene.cells[:] = 254
+    g.load_scene(scene)
+    m.load_scene(scene)
+    c1, b1 = g.score_grid(scene.robot_state, lin, scene.angvels, scene.goal_args)
+    c2, b2 = m.score_grid(scene.robot_state, lin, scene.angvels, scene.goal_args)
+    assert np.array_equal(c1, c2) and b1 == b2 and b2["index"] == -1 and b2["n_valid"] == 0
+
+
+def test_multi_argument_errors(hip_mod):
+    import ctypes as C
+
+    from social_force_window_planner_amd._abi import SFW_ERR_INVALID_ARG
+
+    L = hip_mod.lib()
+    p = default_params()
+    h = C.c_void_p()
+    two = (C.c_int * 2)(0, 0)
+    assert L.sfw_multi_create(C.byref(p), two, 2, SFW_MULTI_RCCL, C.byref(h)) == SFW_ERR_INVALID_ARG  # one rank per device
+    assert L.sfw_multi_create(C.byref(p), two, 0, SFW_MULTI_RCCL, C.byref(h)) == SFW_ERR_INVALID_ARG
+    assert L.sfw_multi_create(C.byref(p), None, 1, SFW_MULTI_RCCL, C.byref(h)) == SFW_ERR_INVALID_ARG
+    bad = (C.c_int * 1)(99)
+    assert L.sfw_multi_create(C.byref(p), bad, 1, SFW_MULTI_HOST_REDUCE, C.byref(h)) != 0 and not h.value
+    assert L.sfw_multi_destroy(None) == 0 and L.sfw_multi_ranks(None) == 0
+
+
+@pytest.mark.parametrize("devices,host_reduce", [((0,), False), ((0, 0), True)])
+def test_host_planner_on_several_ranks(oracle_mod, devices, host_reduce):
+    """The C++ SFWPlanner in multi-device mode drives exactly like the single-device planner and the oracle."""
+    from social_force_window_planner_amd import host
+    from social_force_window_planner_amd._abi import BRANCH_GRID, default_ctrl_params
+
+    host.build()
+    scene = syn.make_scene("ref5x9")
+    ctrl = default_ctrl_params()
+    single = host.HostPlanner(ctrl, scene)
+    multi = host.HostPlanner(ctrl, scene)
+    multi.set_devices(list(devices), host_reduce)
+    lin, ang = syn.generalised_sampler(12, 9)
+    plan = [[x, 0.15 * x, 0.2] for x in np.linspace(0.0, 4.0, 17)]
+    for pl in (single, multi):
+        pl.set_sample_sets(lin, ang)
+        pl.update_plan(plan)
+    pose, vel = np.array([0.0, 0.0, 0.0]), np.array([0.3, 0.0, 0.0])
+    for _ in range(4):
+        rs, rm = single.find_best_action(pose, vel), multi.find_best_action(pose, vel)
+        assert rs[0] == rm[0] and rs[2] == rm[2] == BRANCH_GRID and np.array_equal(rs[1], rm[1])
+        assert np.array_equal(single.last_costs(), multi.last_costs())
+        cmd = rs[1]
+        pose = pose + np.array([cmd[0] * math.cos(pose[2]) * 0.3, cmd[0] * math.sin(pose[2]) * 0.3, cmd[2] * 0.3])
+        vel = np.array([cmd[0], 0.0, cmd[2]])
+    assert multi.ranks() == len(devices)
+    a1, n1 = single.all_trajectories(len(lin) * len(ang), 40)
+    a2, n2 = multi.all_trajectories(len(lin) * len(ang), 40)
+    assert np.array_equal(n1, n2) and np.array_equal(a1, a2)
+    idx = int(np.flatnonzero(multi.last_costs() >= 0)[-1])
+    assert np.array_equal(single.trajectory_points(idx), multi.trajectory_points(idx))
+
+
+def test_cpp_multi_device_example():
+    """examples/multi_device.cpp: a C++ caller of sfw_multi_* (R = 1 over RCCL, R = 2 host reduce) against
+    sfw_score_grid on the same inputs."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "social_force_window_planner_amd", "csrc"), "multidemo"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([os.path.join(ROOT, "build", "multi_device")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rccl R=1: identical" in r.stdout and "host-reduce R=2: identical" in r.stdout
