@@ -206,8 +206,8 @@ int check_params(sfw_handle h, const sfw_params *p) {
     return fail(h, SFW_ERR_INVALID_ARG, "unknown precision");
   if (!(p->sfm_gamma > 0) || !(p->sfm_relaxation_time > 0) || !(p->sfm_force_sigma_obstacle > 0))
     return fail(h, SFW_ERR_INVALID_ARG, "sfm gamma/relaxation_time/sigma must be > 0");
-  if (!(p->sfm_force_factor_social >= 0))
-    return fail(h, SFW_ERR_INVALID_ARG, "sfm_force_factor_social must be >= 0");
+  if (!(p->sfm_force_factor_social >= 0) || !(p->sfm_force_factor_obstacle >= 0))
+    return fail(h, SFW_ERR_INVALID_ARG, "sfm_force_factor_social / _obstacle must be >= 0");
   return SFW_OK;
 }
 

@@ -36,7 +36,7 @@ struct __attribute__((aligned(16))) sfw_agent_const {
 // derived on the device (a division, a product) is a VALU result and would sit in a VGPR pair
 // of every lane for the whole rollout.
 template <typename R> struct sfw_force_k {
-  R lambda, neg_inv_gamma, ln_f_social, c_vel, c_ang, f_obstacle, inv_sigma;  // c_vel = -(n' gamma)^2, c_ang = -(n gamma)^2
+  R lambda, neg_inv_gamma, ln_f_social, c_vel, c_ang, ln_f_obstacle, inv_sigma;  // c_vel = -(n' gamma)^2, c_ang = -(n gamma)^2
 };
 struct sfw_derived {
   sfw_force_k<double> d;

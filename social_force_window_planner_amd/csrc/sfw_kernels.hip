@@ -430,7 +430,7 @@ template <typename R> struct sfm_consts {
 };
 // Constants of the per-agent pass (desired / obstacle / group forces, integration, contact test): read late.
 struct agent_consts {
-  double f_desired, inv_tau, dt, rr, inv_O, f_obstacle, inv_sigma;
+  double f_desired, inv_tau, dt, rr, inv_O, ln_f_obstacle, inv_sigma;
   double f_gaze, f_coherence, f_repulsion;
   int O, robot_id;
 };
@@ -441,7 +441,7 @@ __device__ __forceinline__ agent_consts load_agent_consts(late_launch La, bool f
   c.dt = La->dt;
   c.rr = La->k.rr;
   c.inv_O = La->k.inv_O;
-  c.f_obstacle = f32 ? static_cast<double>(La->k.f.f_obstacle) : La->k.d.f_obstacle;
+  c.ln_f_obstacle = f32 ? static_cast<double>(La->k.f.ln_f_obstacle) : La->k.d.ln_f_obstacle;
   c.inv_sigma = f32 ? static_cast<double>(La->k.f.inv_sigma) : La->k.d.inv_sigma;
   c.f_gaze = La->p.sfm_force_factor_group_gaze;
   c.f_coherence = La->p.sfm_force_factor_group_coherence;
@@ -532,26 +532,53 @@ __device__ __forceinline__ void desired_force(const agent_consts &k, double px, 
   }
 }
 
-// obstacleForce of one agent: mean over the shared laser points (lightsfm
-// computeObstacleForce).  obs lives in LDS; every lane reads the same address
-// (broadcast).
+// obstacleForce of one agent: mean over the shared laser points (lightsfm computeObstacleForce; SURVEY.md
+// Appendix A): (1/O) sum_o k exp(-(|p - o| - radius)/sigma) (p - o)/|p - o|.  The factor k rides in the exponent.
+//
+// Summation order (the same in both kernel organisations, so that they stay bit-identical): the points are cut
+// into OBS_SEG = 8 consecutive segments of L = ceil(O / 8) points; a segment's terms are added in point order
+// starting from 0, the segment sums are added in segment order.  The register-resident form runs the segments
+// one after the other on the agent's lane; the flat form gives every agent eight lanes, one per segment, and
+// adds the eight partial sums in order (the per-agent pass of a small agent set — a control cycle of the
+// reference's own 5 x 9 grid with a few people and 60..240 laser points — otherwise runs the whole O-point
+// loop on the few lanes that own an agent).
+constexpr int OBS_SEG = 8;
 template <typename R>
-__device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const agent_consts &c, const double2 *obs,
-                                               double px, double py, double radius, double &fx, double &fy) {
+__device__ __forceinline__ void obstacle_segment(const sfm_consts<R> &k, const double2 *obs, int o_begin, int o_end,
+                                                 double px, double py, R c0, R neg_inv_sigma, R &ax, R &ay) {
   using namespace sfwm;
-  R ax = R(0), ay = R(0);
-  const R f_obstacle = static_cast<R>(c.f_obstacle), inv_sigma = static_cast<R>(c.inv_sigma);
-  for (int o = 0; o < c.O; ++o) {
+  ax = R(0);
+  ay = R(0);
+  for (int o = o_begin; o < o_end; ++o) {
     const double2 q = obs[o];
     const R mx = R(px - q.x), my = R(py - q.y);
     R rm, mn;
-    rsqrt_sqrt(fmax(fma(mx, mx, my * my), tiny_of<R>::v), rm, mn);
-    const R e = f_obstacle * exp_fast(k.pc, (R(radius) - mn) * inv_sigma);  // exp(-(|md| - radius)/sigma)
-    ax = fma(e * rm, mx, ax);
-    ay = fma(e * rm, my, ay);
+    rsqrt_sqrt(fma(mx, mx, fma(my, my, tiny_of<R>::v)), rm, mn);
+    const R e = exp_fast(k.pc, fma(mn, neg_inv_sigma, c0)) * rm;  // k exp(-(|md| - radius)/sigma) / |md|
+    ax = fma(e, mx, ax);
+    ay = fma(e, my, ay);
   }
-  fx = static_cast<double>(ax) * c.inv_O;
-  fy = static_cast<double>(ay) * c.inv_O;
+}
+// c0 of an agent: radius / sigma + ln k
+template <typename R> __device__ __forceinline__ R obstacle_c0(const agent_consts &c, double radius) {
+  return static_cast<R>(fma(radius, c.inv_sigma, c.ln_f_obstacle));
+}
+// all eight segments on one lane
+template <typename R>
+__device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const agent_consts &c, const double2 *obs,
+                                               double px, double py, double radius, double &fx, double &fy) {
+  const int O = c.O, L = (O + OBS_SEG - 1) / OBS_SEG;
+  const R c0 = obstacle_c0<R>(c, radius), nis = static_cast<R>(-c.inv_sigma);
+  R tx = R(0), ty = R(0);
+  for (int seg = 0; seg < OBS_SEG; ++seg) {
+    const int b = seg * L, e = min(b + L, O);
+    R ax, ay;
+    obstacle_segment<R>(k, obs, b, e, px, py, c0, nis, ax, ay);
+    tx = seg == 0 ? ax : tx + ax;
+    ty = seg == 0 ? ay : ty + ay;
+  }
+  fx = static_cast<double>(tx) * c.inv_O;
+  fy = static_cast<double>(ty) * c.inv_O;
 }
 
 // LDS map of one wave.  Agent state lives in PLANES of `cap` doubles each — px, py, vx, vy, the force
@@ -569,6 +596,8 @@ struct lds_layout {
   sfw_robot_step *rsb;  // robot records: one per sample of the wave (register form), two (flat form: this step's
                         // and the prefetched next step's)
   double *gr, *dv, *rad, *swp;
+  double2 *opart;       // flat form with laser points: the 64 lanes' partial obstacle sums of one pass
+  double *wr;           // flat form with laser points: the robot's social-work term waiting for its obstacle part
   int *id, *hasgoal, *dead, *grp, *goff, *gmem;
   size_t bytes;
   __host__ __device__ lds_layout(char *base, int A, int cap, int GA, int G, int O, int NG, int NM, bool consts,
@@ -591,6 +620,8 @@ struct lds_layout {
     obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? O : 1)));
     rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * (with_frc ? 2 : G)));
     swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
+    opart = reinterpret_cast<double2 *>(take(sizeof(double2) * ((with_frc && O > 0) ? 64 : 0)));
+    wr = reinterpret_cast<double *>(take(sizeof(double) * ((with_frc && O > 0) ? 2 : 0)));
     hasgoal = reinterpret_cast<int *>(take(sizeof(int) * GA));
     dead = reinterpret_cast<int *>(take(sizeof(int) * G));
     const int Ac = consts ? A : 0;
@@ -701,6 +732,7 @@ template <typename R, bool PIN_ALL> __device__ __forceinline__ sfm_consts<R> mak
 // overwrite is the caller's), contact test, social-work terms, next step's
 // desired+obstacle force.  F = total force on the agent at the pre-step state
 // (for the robot: its social force only).  Returns this slot's social work.
+// The laser-point term is the caller's: `work` lacks the robot's obstacle part and (nfx, nfy) a person's obstacle force.
 template <typename R>
 __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const agent_consts &c, const lds_layout &s,
                                              const sfw_robot_step &rs, const agent_k &ak, int step, int i, int g,
@@ -742,19 +774,6 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const agent
     }
     // desired force at the new state: with the obstacle term below, the next step's starting force
     desired_force(c, px, py, vx, vy, hg != 0, ak.gx, ak.gy, ak.gr, ak.dv, nfx, nfy);
-  }
-  if (c.O > 0) {
-    // Obstacle term, ONE loop over the laser points for every lane of the wave: the robot needs it at its
-    // pre-step position (Wr's obstacle part), a person at its new position.  A call in each branch would run
-    // the O-point loop twice per wave (the branches diverge): measured 55 instead of 30 issue slots per point.
-    double ox, oy;
-    obstacle_force<R>(k, c, s.obs, px, py, ak.rad, ox, oy);
-    if (robot) {
-      work += fast_norm(ox, oy);
-    } else {
-      nfx += ox;
-      nfy += oy;
-    }
   }
   // The robot's own state is overwritten with its post-step record (ref :600-604) by the caller,
   // after this function: here it would keep the record live across the obstacle loop.
@@ -1046,6 +1065,9 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
 
     // ---- per-agent pass ---------------------------------------------------
     const agent_consts c = load_agent_consts(late_args(), F32);
+    // (1) integration, contact test, Wp, desired force; a person's new state goes to LDS, the robot keeps its
+    // pre-step position there until the laser-point term (2) has been evaluated at it
+    const bool with_obs = c.O > 0;
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
       if (ok_[r] && s.dead[g_[r]] == 0) {
@@ -1053,24 +1075,52 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         const sfw_robot_step rs = s.rsb[g_[r]];
         double px = s.px[sl], py = s.py[sl], vx = s.vx[sl], vy = s.vy[sl];
         double nfx, nfy;
-        sw[r] += agent_step<R>(k, c, s, rs, agent_k_lds(s, i_[r]), step, i_[r], g_[r], sl, px, py, vx, vy,
-                               fx[r] - s.fjx[sl], fy[r] - s.fjy[sl], nfx, nfy);
+        const double w = agent_step<R>(k, c, s, rs, agent_k_lds(s, i_[r]), step, i_[r], g_[r], sl, px, py, vx, vy,
+                                       fx[r] - s.fjx[sl], fy[r] - s.fjy[sl], nfx, nfy);
         fx[r] = nfx;
         fy[r] = nfy;
-        if (i_[r] == 0) {  // the robot does not move by SFM: post-step record (ref :600, :604 robot-local twist)
-          const sfw_robot_step r2 = s.rsb[g_[r]];
-          px = r2.x;
-          py = r2.y;
-          vx = r2.vx;
-          vy = r2.vy;
+        if (i_[r] == 0 && with_obs) {
+          s.swp[sl] = w;  // Wr = social part + obstacle part, summed in (2) before it joins the social work
+        } else {
+          sw[r] += w;
         }
-        s.px[sl] = px;
-        s.py[sl] = py;
-        s.vx[sl] = vx;
-        s.vy[sl] = vy;
+        if (i_[r] == 0) {  // the robot does not move by SFM: post-step record (ref :600, :604 robot-local twist)
+          px = rs.x;
+          py = rs.y;
+          vx = rs.vx;
+          vy = rs.vy;
+        }
+        if (!(i_[r] == 0 && with_obs)) {
+          s.px[sl] = px;
+          s.py[sl] = py;
+          s.vx[sl] = vx;
+          s.vy[sl] = vy;
+        }
         s.fjx[sl] = 0.0;
         s.fjy[sl] = 0.0;
       }
+    }
+    // (2) obstacle term, ONE loop over the laser points for every lane of the wave: the robot needs it at its
+    // pre-step position (Wr's obstacle part), a person at its new position (next starting force)
+    if (with_obs) {
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+        if (ok_[r] && s.dead[g_[r]] == 0) {
+          const int sl = sl_[r];
+          double ox, oy;
+          obstacle_force<R>(k, c, s.obs, s.px[sl], s.py[sl], s.rad[i_[r]], ox, oy);
+          if (i_[r] == 0) {
+            sw[r] += s.swp[sl] + fast_norm(ox, oy);
+            const sfw_robot_step r2 = s.rsb[g_[r]];
+            s.px[sl] = r2.x;
+            s.py[sl] = r2.y;
+            s.vx[sl] = r2.vx;
+            s.vy[sl] = r2.vy;
+          } else {
+            fx[r] += ox;
+            fy[r] += oy;
+          }
+        }
     }
     __syncthreads();
     bool any_live = false;
@@ -1156,10 +1206,10 @@ __device__ __forceinline__ void wait_pair_entries(uint32_t &io, uint32_t &jo) {
 }
 
 #ifndef SFW_FLAT_WAVES
-#define SFW_FLAT_WAVES 1  // tuning knob (csrc/Makefile EXTRA): minimum waves per SIMD the flat kernel is compiled for
+#define SFW_FLAT_WAVES 5  // waves per SIMD the flat kernel is compiled for (<= 96 VGPRs; tuning knob, csrc/Makefile EXTRA)
 #endif
 template <typename R, bool GROUPS, int CAP>
-__global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
+__global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVES) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   (void)G_unused;
   const int lane = threadIdx.x;
@@ -1307,27 +1357,87 @@ __global__ void __launch_bounds__(WAVE, GROUPS ? 1 : SFW_FLAT_WAVES) sfw_social_
     const sfw_agent_const *const agent_c = La->agent_c;
     const sfw_robot_step rs = s.rsb[step & 1];
     if (step + 1 < step_end) fetch_robot(La->rstep, La->rstep_stride, step + 1, (step + 1) & 1);
+    const bool with_obs = c.O > 0;
     for (int sl = lane; sl < A; sl += WAVE) {
       const agent_k ak = GROUPS ? agent_k_lds(s, sl) : agent_k_global(agent_c, sl);
       double px = s.px[sl], py = s.py[sl], vx = s.vx[sl], vy = s.vy[sl];
       double nfx, nfy;
       const double w = agent_step<R>(k, c, s, rs, ak, step, sl, 0, sl, px, py, vx, vy, s.fcx[sl] - s.fjx[sl],
-                                     s.fcy[sl] - s.fjy[sl], nfx, nfy);
-      s.swp[sl] += w;
+                                            s.fcy[sl] - s.fjy[sl], nfx, nfy);
+      if (sl == 0 && with_obs) {
+        *s.wr = w;  // Wr = social part + obstacle part: summed below, then added to the robot's social work
+      } else {
+        s.swp[sl] += w;
+      }
       if (sl == 0) {  // the robot does not move by SFM: post-step record (ref :600, :604 robot-local twist)
         px = rs.x;
         py = rs.y;
         vx = rs.vx;
         vy = rs.vy;
       }
-      s.px[sl] = px;
-      s.py[sl] = py;
-      s.vx[sl] = vx;
-      s.vy[sl] = vy;
+      if (!(sl == 0 && with_obs)) {  // with laser points the robot keeps its pre-step position until their pass is done
+        s.px[sl] = px;
+        s.py[sl] = py;
+        s.vx[sl] = vx;
+        s.vy[sl] = vy;
+      }
       s.fcx[sl] = nfx;
       s.fcy[sl] = nfy;
       s.fjx[sl] = 0.0;
       s.fjy[sl] = 0.0;
+    }
+    if (with_obs) {
+      // Obstacle term: the robot at its pre-step position (Wr's obstacle part), a person at its new position.
+      // Few agents: eight lanes per agent, one per segment of the laser points; many: the agent's lane runs the
+      // eight segments itself (same sums in the same order, see obstacle_force).  8 lanes pay from ~A <= 48 on.
+      __syncthreads();
+      auto apply = [&](int a, double ox, double oy) {
+        if (a == 0) {
+          s.swp[0] += *s.wr + fast_norm(ox, oy);
+        } else {
+          s.fcx[a] += ox;
+          s.fcy[a] += oy;
+        }
+      };
+      if (A <= 48) {
+        const int L8 = (c.O + OBS_SEG - 1) / OBS_SEG, seg = lane & (OBS_SEG - 1);
+        const int ob = seg * L8, oe = min(ob + L8, c.O);
+        const R nis = static_cast<R>(-c.inv_sigma);
+        for (int a0 = 0; a0 < A; a0 += WAVE / OBS_SEG) {
+          const int a = a0 + (lane >> 3);
+          R ax = R(0), ay = R(0);
+          if (a < A) {
+            const double rad = GROUPS ? s.rad[a] : agent_c[a].radius;
+            obstacle_segment<R>(k, s.obs, ob, oe, s.px[a], s.py[a], obstacle_c0<R>(c, rad), nis, ax, ay);
+          }
+          s.opart[lane] = double2{static_cast<double>(ax), static_cast<double>(ay)};
+          __syncthreads();
+          if (a < A && seg == 0) {
+            R tx = static_cast<R>(s.opart[lane].x), ty = static_cast<R>(s.opart[lane].y);
+#pragma unroll
+            for (int q = 1; q < OBS_SEG; ++q) {
+              tx += static_cast<R>(s.opart[lane + q].x);
+              ty += static_cast<R>(s.opart[lane + q].y);
+            }
+            apply(a, static_cast<double>(tx) * c.inv_O, static_cast<double>(ty) * c.inv_O);
+          }
+          __syncthreads();
+        }
+      } else {
+        for (int a = lane; a < A; a += WAVE) {
+          const double rad = GROUPS ? s.rad[a] : agent_c[a].radius;
+          double ox, oy;
+          obstacle_force<R>(k, c, s.obs, s.px[a], s.py[a], rad, ox, oy);
+          apply(a, ox, oy);
+        }
+        __syncthreads();
+      }
+      if (lane == 0) {
+        s.px[0] = rs.x;
+        s.py[0] = rs.y;
+        s.vx[0] = rs.vx;
+        s.vy[0] = rs.vy;
+      }
     }
     __syncthreads();
     if (s.dead[0] != 0) break;
@@ -1469,7 +1579,7 @@ __global__ void __launch_bounds__(64) sfw_key_table_kernel(const sfw_sel *sel, d
 // All organisations produce bit-identical costs (tools/kernel_equiv.py), so the choice
 // never shows in the results.
 struct wave_plan { int G; int ns; bool flat; };
-static wave_plan plan_for(int A, int64_t T) {
+static wave_plan plan_for(int A, int64_t T, int O = 0) {
   wave_plan best{1, 0, true};
   if (A <= 0) return wave_plan{1, 1, false};
   const int P = A * (A - 1) / 2;
@@ -1482,10 +1592,11 @@ static wave_plan plan_for(int A, int64_t T) {
     const double sc = 0.95 * A / (2.0 * WAVE);
     if (sc >= best_score) { best_score = sc; best = wave_plan{1, 2, false}; }
   }
-  if (T <= 4096 && A >= 2) best = wave_plan{1, 0, true};
+  // ... and a robot alone among laser points: the flat form spreads the points over eight lanes
+  if (T <= 4096 && (A >= 2 || O > 0)) best = wave_plan{1, 0, true};
   static const char *const e = getenv("SFW_FORCE_FLAT");  // tuning override, read once
   if (e) {
-    if (atoi(e) == 1 && A >= 2) best = wave_plan{1, 0, true};
+    if (atoi(e) == 1 && (A >= 2 || O > 0)) best = wave_plan{1, 0, true};
     if (atoi(e) == 0 && A <= 2 * WAVE) best = (A <= WAVE) ? wave_plan{WAVE / A, 1, false} : wave_plan{1, 2, false};
   }
   return best;
@@ -1501,7 +1612,8 @@ void sfw_derive(sfw_launch &L) {
   d.ln_f_social = std::log(p.sfm_force_factor_social);  // -inf for Fs = 0: the clamp at -800 makes the force 0
   d.c_vel = -(p.sfm_n_prime * p.sfm_n_prime) * (p.sfm_gamma * p.sfm_gamma);
   d.c_ang = -(p.sfm_n * p.sfm_n) * (p.sfm_gamma * p.sfm_gamma);
-  d.f_obstacle = p.sfm_force_factor_obstacle;
+  // ln of the obstacle force factor (it rides in the exponent); a factor of 0 becomes exp(-700) = 1e-304
+  d.ln_f_obstacle = p.sfm_force_factor_obstacle > 0 ? std::log(p.sfm_force_factor_obstacle) : -700.0;
   d.inv_sigma = 1.0 / p.sfm_force_sigma_obstacle;
   sfw_force_k<float> &f = L.k.f;
   f.lambda = static_cast<float>(d.lambda);
@@ -1509,7 +1621,7 @@ void sfw_derive(sfw_launch &L) {
   f.ln_f_social = static_cast<float>(d.ln_f_social);
   f.c_vel = static_cast<float>(d.c_vel);
   f.c_ang = static_cast<float>(d.c_ang);
-  f.f_obstacle = static_cast<float>(d.f_obstacle);
+  f.ln_f_obstacle = static_cast<float>(d.ln_f_obstacle);
   f.inv_sigma = static_cast<float>(d.inv_sigma);
   L.k.f_desired = p.sfm_force_factor_desired;
   L.k.inv_tau = 1.0 / p.sfm_relaxation_time;
@@ -1533,8 +1645,8 @@ static size_t lds_bytes_for(const wave_plan &pl, int A, int O, int NG, int n_grp
 // Largest LDS allocation any launch of a chunk of T samples may ask for (the prefix phase of the
 // shared-prefix rollout may pick the flat organisation where the chunk itself uses the other).
 size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T) {
-  const size_t a = lds_bytes_for(plan_for(A, T), A, O, NG, n_grp_mem);
-  const size_t b = A >= 2 ? lds_bytes_for(wave_plan{1, 0, true}, A, O, NG, n_grp_mem) : 0;
+  const size_t a = lds_bytes_for(plan_for(A, T, O), A, O, NG, n_grp_mem);
+  const size_t b = (A >= 2 || O > 0) ? lds_bytes_for(wave_plan{1, 0, true}, A, O, NG, n_grp_mem) : 0;
   return a > b ? a : b;
 }
 
@@ -1604,7 +1716,7 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L,
   // organisation-neutral, so every launch picks its own by its item count (measured: forcing the
   // flat form on an under-filled prefix phase at cfg2 — 2024 register-form waves — changes nothing).
   const int64_t items = L.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L.n_cls) : L.chunk_count;
-  const wave_plan pl = plan_for(L.A, items);
+  const wave_plan pl = plan_for(L.A, items, L.O);
   const unsigned grid = static_cast<unsigned>((items + pl.G - 1) / pl.G);
   const size_t lds = lds_bytes_for(pl, L.A, L.O, L.NG, L.n_grp_mem);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
