@@ -16,7 +16,6 @@
 #include <cstring>
 #include <limits>
 #include <new>
-#include <map>
 #include <string>
 #include <vector>
 
@@ -275,32 +274,40 @@ double new_velocity_host(double vg, double vi, double a_max, double dt) {
 // Classes of the samples' velocity sequences after 1..max_p steps: cls[p-1][i] is the class of
 // sample value i when the first p velocities are compared, counts[p-1] the number of classes.
 // Stops early once every value is its own class (nothing left to share from there on): cls/counts
-// may hold fewer than max_p levels.  Runs on the control-cycle path: sort-based, no allocation per step.
+// may hold fewer than max_p levels.  Runs on the control-cycle path, so it avoids a sort per level:
+// new_velocity is monotone in the target (and in the previous velocity), hence so is every v_p, and
+// the samples that share a sequence are CONTIGUOUS when ordered by target — one sort up front, then a
+// run-length pass per level.  (Were they not, the result would only be more classes, never a wrong
+// merge: two samples share a class only if all their compared velocities are bit-equal.)
 void velocity_classes(const std::vector<double> &targets, double v0, double a_max, double dt, int max_p,
                       std::vector<std::vector<int32_t>> &cls, std::vector<int32_t> &counts) {
-  struct key { int32_t cls; int32_t idx; uint64_t bits; };
   const size_t n = targets.size();
-  std::vector<double> v(n, v0);
-  std::vector<int32_t> cur(n, 0);
-  std::vector<key> keys(n);
+  std::vector<int32_t> order(n);
+  for (size_t i = 0; i < n; ++i) order[i] = static_cast<int32_t>(i);
+  std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+    return targets[static_cast<size_t>(a)] != targets[static_cast<size_t>(b)] ? targets[static_cast<size_t>(a)] < targets[static_cast<size_t>(b)]
+                                                                                : a < b;
+  });
+  std::vector<double> t(n), v(n, v0);
+  for (size_t k = 0; k < n; ++k) t[k] = targets[static_cast<size_t>(order[k])];
+  std::vector<int32_t> cur(n, 0), nxt(n);
   cls.clear();
   counts.clear();
   for (int p = 0; p < max_p; ++p) {
-    for (size_t i = 0; i < n; ++i) {
-      v[i] = new_velocity_host(targets[i], v[i], a_max, dt);
-      keys[i].cls = cur[i];
-      keys[i].idx = static_cast<int32_t>(i);
-      std::memcpy(&keys[i].bits, &v[i], sizeof(uint64_t));
-    }
-    std::sort(keys.begin(), keys.end(), [](const key &a, const key &b) {
-      return a.cls != b.cls ? a.cls < b.cls : a.bits != b.bits ? a.bits < b.bits : a.idx < b.idx;
-    });
     int32_t id = -1;
+    uint64_t prev_bits = 0;
     for (size_t k = 0; k < n; ++k) {
-      if (k == 0 || keys[k].cls != keys[k - 1].cls || keys[k].bits != keys[k - 1].bits) ++id;
-      cur[static_cast<size_t>(keys[k].idx)] = id;
+      v[k] = new_velocity_host(t[k], v[k], a_max, dt);
+      uint64_t bits;
+      std::memcpy(&bits, &v[k], sizeof(bits));
+      if (k == 0 || cur[k] != cur[k - 1] || bits != prev_bits) ++id;
+      nxt[k] = id;
+      prev_bits = bits;
     }
-    cls.push_back(cur);
+    cur.swap(nxt);
+    cls.emplace_back(n);
+    std::vector<int32_t> &out = cls.back();
+    for (size_t k = 0; k < n; ++k) out[static_cast<size_t>(order[k])] = cur[k];
     counts.push_back(id + 1);
     if (static_cast<size_t>(id + 1) == n) break;
   }
@@ -406,18 +413,19 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   };
   // representatives (first member) of the classes of `cls` over the index range [i0, i1); ids are
   // relabelled in order of first appearance; `local` receives the relabelled class of every index
-  auto relabel = [](const std::vector<int32_t> &cls, int64_t i0, int64_t i1, std::vector<int32_t> &local,
-                    std::vector<int32_t> &rep) {
-    std::map<int32_t, int32_t> ids;
+  std::vector<int32_t> ids;  // class id -> relabelled id of the current range (ids are < the axis length)
+  auto relabel = [&ids](const std::vector<int32_t> &cls, int64_t i0, int64_t i1, std::vector<int32_t> &local,
+                        std::vector<int32_t> &rep) {
+    ids.assign(cls.size(), -1);
     local.clear();
     rep.clear();
     for (int64_t i = i0; i < i1; ++i) {
-      auto it = ids.find(cls[static_cast<size_t>(i)]);
-      if (it == ids.end()) {
-        it = ids.emplace(cls[static_cast<size_t>(i)], static_cast<int32_t>(rep.size())).first;
+      int32_t &id = ids[static_cast<size_t>(cls[static_cast<size_t>(i)])];
+      if (id < 0) {
+        id = static_cast<int32_t>(rep.size());
         rep.push_back(static_cast<int32_t>(i - i0));
       }
-      local.push_back(it->second);
+      local.push_back(id);
     }
   };
   struct axis_level { std::vector<int32_t> local, rep, src; };
