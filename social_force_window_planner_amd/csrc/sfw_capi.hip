@@ -173,7 +173,7 @@ struct sfw_planner_s {
   dev_buf<int16_t> pts_fcode;
   // sfw_set_params bumps params_epoch; the table sizes and the shared-prefix plan carry the epoch they were made for
   uint64_t params_epoch = 1, plan_epoch = 0;
-  size_t table_budget_bytes = size_t(2) << 30;  // K1->K2 robot-step table per chunk
+  size_t table_budget_bytes = size_t(8) << 30;  // K1->K2 per-step tables per chunk (of 288 GB): BASELINE cfg4 runs in one chunk
   pinned_buf pin_map, pin_world, pin_out, pin_cls;
 };
 

@@ -1,5 +1,5 @@
-"""Build profiles/r01_traffic.json from the FETCH_SIZE/WRITE_SIZE summaries written by tools/profile.sh.
-usage: traffic_json.py <workload>=<traffic.txt> ... > profiles/r01_traffic.json
+"""Build profiles/r0N_traffic.json from the FETCH_SIZE/WRITE_SIZE summaries written by tools/profile.sh.
+usage: traffic_json.py <workload>=<traffic.txt> ... > profiles/r02_traffic.json
 The summaries hold means per dispatch; a bench step dispatches K2 several times (shared-prefix levels +
 suffix, possibly in both kernel organisations), so bytes are converted to per-step sums using the
 dispatch counts (one sfw_rollout_kernel dispatch per step)."""
@@ -20,7 +20,7 @@ for arg in sys.argv[1:]:
         if m and cur is not None:
             cur["fetch_bytes" if m.group(1) == "FETCH_SIZE" else "write_bytes"] = float(m.group(2)) * 1024.0
     kernels = {k: v for k, v in kernels.items() if "pair_table" not in k}
-    steps = kernels["sfw_rollout_kernel"]["dispatches"]
+    steps = next(v["dispatches"] for k, v in kernels.items() if k.startswith("sfw_rollout_kernel"))
     per_step = {}
     for k, v in kernels.items():
         n = v["dispatches"] / steps
