@@ -272,9 +272,9 @@ int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth,
  * n_points: count ints = poses the reference's Trajectory would hold: all of them
  * for a valid sample, those before the first illegal footprint pose, or 0..i for a
  * sample rejected by pedestrian contact at step i (0 for the (0,0) sample).
- * Corner not reproduced: a sample that is illegal on the costmap at pose j AND
- * would have touched a pedestrian at an earlier step i reports j poses (the
- * pedestrians of costmap-rejected samples are never integrated). */
+ * A sample that is illegal on the costmap at pose j AND touches a pedestrian at an earlier step i < j
+ * reports i + 1 poses, as the reference does (it returns at the contact, :613-627): when the range holds
+ * costmap-rejected samples their pedestrians are integrated in an extra pass of this call. */
 int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *points_xyth, int32_t *n_points);
 /* Raw HIP stream (hipStream_t) the handle launches on, for callers that want
  * to record their own events. */

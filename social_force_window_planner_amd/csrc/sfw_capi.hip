@@ -166,7 +166,7 @@ struct sfw_planner_s {
   dev_buf<int32_t> n_points;
   dev_buf<char> one_out;  // sfw_score_one: cost | n_points | coll_step | points, contiguous -> one D2H
   // scratch outputs of sfw_grid_points_batch's K1 re-run (kept across calls: hipMalloc/hipFree synchronise the device)
-  dev_buf<int32_t> pts_status;
+  dev_buf<int32_t> pts_status, pts_coll;
   dev_buf<double> pts_base, pts_costs;
   dev_buf<sfw_robot_step> pts_rstep;
   dev_buf<sfw_pose_frame> pts_frame;
@@ -837,6 +837,7 @@ int sfw_destroy(sfw_handle h) {
   h->n_points.release();
   h->one_out.release();
   h->pts_status.release();
+  h->pts_coll.release();
   h->pts_base.release();
   h->pts_costs.release();
   h->pts_rstep.release();
@@ -1029,10 +1030,13 @@ int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp, doubl
   L.n_points = reinterpret_cast<int32_t *>(h->one_out.p + 8);
   L.coll_step = reinterpret_cast<int32_t *>(h->one_out.p + 12);
   L.points = reinterpret_cast<double *>(h->one_out.p + head);
+  const bool want_pts = (points_xyth && points_cap > 0) || n_points;
+  // With points wanted a costmap-rejected sample is integrated too: a pedestrian contact at an earlier step ends the
+  // reference's Trajectory there (ref :613-627 returns before the later illegal pose is ever reached)
+  L.force_alive = want_pts ? 1 : 0;
   SFW_HIP(h, sfw_launch_rollout(L, h->stream));
   SFW_HIP(h, sfw_launch_social(L, h->stream));
-  const bool want_pts = points_xyth && points_cap > 0;
-  const size_t fetch = head + (want_pts ? pts_bytes : 0);
+  const size_t fetch = head + ((points_xyth && points_cap > 0) ? pts_bytes : 0);
   SFW_HIP(h, h->pin_out.reserve(fetch));
   SFW_HIP(h, hipMemcpyAsync(h->pin_out.p, h->one_out.p, fetch, hipMemcpyDeviceToHost, h->stream));
   SFW_HIP(h, hipStreamSynchronize(h->stream));
@@ -1042,7 +1046,7 @@ int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp, doubl
   std::memcpy(&coll, h->pin_out.p + 12, sizeof(coll));
   if (coll >= 0 && coll + 1 < n) n = coll + 1;  // rejected by contact at step `coll`: poses 0..coll were added
   if (n_points) *n_points = n;
-  if (want_pts && n > 0) {
+  if (points_xyth && points_cap > 0 && n > 0) {
     const int m = n < points_cap ? n : points_cap;
     std::memcpy(points_xyth, h->pin_out.p + head, sizeof(double) * 3 * static_cast<size_t>(m));
   }
@@ -1170,6 +1174,28 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
     e = hipMemcpyAsync(points_xyth, h->points.p, sizeof(double) * 3 * S * n, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) return hip_fail(h, e, "grid_points");
+  // A sample whose footprint turns illegal at pose a was never integrated by the grid launch.  If a pedestrian
+  // touches the robot at an earlier step b < a the reference's Trajectory ends there with b + 1 points (ref :613-627
+  // return before pose a is reached): integrate the range once more with those samples kept alive and take their
+  // contact steps from that run.
+  bool rejected = false;
+  for (size_t i = 0; i < n && !rejected; ++i) rejected = n_points[i] < S;
+  if (rejected && h->st_A > 1) {
+    if (int rc = check_lds(h, count)) return rc;
+    SFW_HIP(h, h->pts_coll.reserve(n));
+    sfw_launch L;
+    fill_launch(h, L, first, count, count);
+    L.status = h->pts_status.p - first;
+    L.base_cost = h->pts_base.p - first;
+    L.costs = h->pts_costs.p - first;
+    L.coll_step = h->pts_coll.p - first;
+    L.rstep = h->pts_rstep.p;
+    L.force_alive = 1;
+    SFW_HIP(h, hipMemsetAsync(h->pts_coll.p, 0xff, sizeof(int32_t) * n, h->stream));  // -1: no contact
+    SFW_HIP(h, sfw_launch_social(L, h->stream));
+    SFW_HIP(h, hipMemcpyAsync(coll.data(), h->pts_coll.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    SFW_HIP(h, hipStreamSynchronize(h->stream));
+  }
   // a trajectory rejected by contact at step i holds the poses 0..i (addPoint precedes the test, ref :578, :613-627)
   for (size_t i = 0; i < n; ++i)
     if (coll[i] >= 0 && coll[i] + 1 < n_points[i]) n_points[i] = coll[i] + 1;

@@ -105,6 +105,7 @@ struct sfw_launch {
   int32_t phase;                 // SFW_PHASE_*
   int32_t step_begin, step_end;  // steps this launch integrates
   int32_t resume;                // 1: start from in_state records instead of the initial agents
+  int32_t force_alive;           // 1: K2 also integrates samples K1 rejected on the costmap (point dumps only)
   int32_t n_cls, n_col_cls;      // PREFIX: classes of this level, its column classes
   const int32_t *row_rep;        // PREFIX [row classes]  chunk-local row whose robot records represent the class
   const int32_t *col_rep;        // PREFIX [n_col_cls]    column likewise

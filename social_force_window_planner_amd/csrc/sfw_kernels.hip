@@ -834,7 +834,10 @@ __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout
         // a class is simulated whatever K1 said about its members, unless its parent already ended in a contact
         dead = L.resume ? L.in_dead[source_class_of_item(L, first_local + lane)] : 0;
       } else {
-        dead = (L.status[L.chunk_begin + first_local + lane] != SFW_ST_VALID);
+        const int st = L.status[L.chunk_begin + first_local + lane];
+        // force_alive (Trajectory-point dumps): a sample the costmap rejected at pose a is integrated all the same, so
+        // that a pedestrian contact at an earlier step b < a is found (the reference returns there, ref :613-627)
+        dead = L.force_alive ? (st == SFW_ST_SKIPPED) : (st != SFW_ST_VALID);
         if (L.resume && dead == 0) dead = L.in_dead[source_class_of_item(L, first_local + lane)];
       }
     }
@@ -860,7 +863,9 @@ __device__ __forceinline__ void finish_wave(const lds_layout &s, int lane, int G
   auto put = [&](int g, double v) {
     const int64_t t = t0 + g;
     const int d = s.dead[g];
-    if (d == 0) costs[t] = base_cost[t] + social_weight * v;
+    if (d == 0) {
+      if (status[t] == SFW_ST_VALID) costs[t] = base_cost[t] + social_weight * v;  // not VALID: force_alive run of a costmap-rejected sample
+    }
     else if (d >= 2) {
       costs[t] = SFW_COST_INVALID;
       status[t] = SFW_ST_INVALID;

@@ -312,3 +312,55 @@ def test_set_params_between_stage_and_launch(oracle_mod, hip_mod, monkeypatch):
     fresh3.load_scene(scene)
     c3f, b3f = fresh3.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
     assert np.array_equal(c3, c3f) and b3 == b3f
+
+
+# ---------------------------------------------------------------------------
+# Trajectory points of a doubly rejected sample (VERDICT r1 "missing" 5)
+# ---------------------------------------------------------------------------
+def test_points_of_a_sample_rejected_by_contact_before_its_illegal_pose(oracle_mod, hip_mod):
+    """A wall the robot reaches late and a pedestrian it touches earlier: the reference's Trajectory ends at the
+    contact (b + 1 points, ref :613-627), not at the first illegal footprint pose a > b (ref :545-573).  Both the
+    batched dump of a scored grid and sfw_score_one must report that."""
+    w = dataclasses.replace(syn.WORKLOADS["ref5x9"], n_people=2, sim_time=2.0, seed=77)
+    scene = syn.make_scene(w)
+    scene.cells[:] = 0
+    col = int((1.25 - scene.origin_x) / scene.resolution)
+    scene.cells[:, col:col + 3] = 254          # a wall at x = 1.25 m
+    ag = scene.agents
+    for i, (x, y) in ((1, (0.85, 0.05)), (2, (0.9, -0.45))):   # two people walking towards the robot
+        ag[i].x, ag[i].y, ag[i].vx, ag[i].vy = x, y, -0.3, 0.0
+        ag[i].goal_x, ag[i].goal_y = x - 2.0, y
+    p = default_params(sim_time=2.0)
+    S = 80
+    o = oracle_mod.OracleScorer(p)
+    o.load_scene(scene)
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    lin, ang = scene.linvels, scene.angvels
+    gc, gb = g.score_grid(scene.robot_state, lin, ang, scene.goal_args)
+    pts, cnt = g.grid_points_batch(0, len(lin) * len(ang), S)
+    # the same scene without people: where the costmap alone would end each trajectory
+    import copy
+    bare = syn.make_scene(dataclasses.replace(w, n_people=0))
+    bare.cells[:] = scene.cells
+    ob = oracle_mod.OracleScorer(p)
+    ob.load_scene(bare)
+    n_double = 0
+    for i in range(1, len(lin) * len(ang)):
+        vx, vth = lin[i // len(ang)], ang[i % len(ang)]
+        co, po = o.score_one(scene.robot_state, vx, 0.0, vth, scene.goal_args)
+        cb, pb = ob.score_one(scene.robot_state, vx, 0.0, vth, scene.goal_args)
+        assert cnt[i] == len(po), (i, cnt[i], len(po), len(pb))
+        assert np.allclose(pts[i, :cnt[i]], po, atol=1e-13)
+        assert (gc[i] < 0) == (co < 0)
+        if cb < 0 and co < 0 and len(po) < len(pb):
+            n_double += 1                     # illegal pose at len(pb), contact already at step len(po) - 1
+            cg, pg = g.score_one(scene.robot_state, vx, 0.0, vth, scene.goal_args)
+            assert cg == -1.0 and pg.shape == po.shape and np.allclose(pg, po, atol=1e-13)
+    assert n_double >= 3, f"scene does not exercise the corner (only {n_double} doubly rejected samples)"
+    # the grid results are untouched by the dump
+    gc2, gb2, _ = None, None, None
+    g.stage(scene.robot_state, lin, ang, scene.goal_args)
+    g.launch()
+    gc2, gb2, _ = g.fetch()
+    assert np.array_equal(gc, gc2) and gb == gb2
