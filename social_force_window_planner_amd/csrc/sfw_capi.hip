@@ -112,6 +112,8 @@ struct sfw_planner_s {
   // ordered pairs (i, j) of agents with equal velocities at hand-over (e.g. standing people): see rest_forces
   std::vector<std::pair<int32_t, int32_t>> rest_pairs;
   const double *d_agent_rest = nullptr;  // A x (fx, fy) in `world`, or null when there is no such pair
+  std::vector<std::pair<int32_t, int32_t>> st_rest_pairs;  // what the last stage evaluated them from: sfw_set_params
+  std::vector<double> st_rest_pv;                           // between stage and launch re-evaluates (pos | vel, 4A doubles)
   // what the last stage uploaded (sfw_set_* after a stage take effect at the next stage; a launch
   // in between must keep describing the device copy)
   int st_K = 0, st_A = 0, st_O = 0, st_NG = 0, st_n_grp_mem = 0;
@@ -500,12 +502,10 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
 // is evaluated here, once per stage, with the same expression sequence and the same libm the reference would
 // run on this host (computeSocialForce), and added to the agents' starting forces.
 // out: A x (fx, fy).
-void rest_forces(const sfw_planner_s *h, double *out) {
-  const char *base = h->h_agents.data();
-  const double *pos = reinterpret_cast<const double *>(base), *vel = reinterpret_cast<const double *>(base + h->ao_vel);
-  const sfw_params &p = h->params;
-  for (int i = 0; i < 2 * h->A; ++i) out[i] = 0.0;
-  for (const auto &pr : h->rest_pairs) {
+void rest_forces(const sfw_params &p, const std::vector<std::pair<int32_t, int32_t>> &pairs, const double *pos, const double *vel,
+                 int A, double *out) {
+  for (int i = 0; i < 2 * A; ++i) out[i] = 0.0;
+  for (const auto &pr : pairs) {
     const int i = pr.first, j = pr.second;
     const double dx = pos[2 * j] - pos[2 * i], dy = pos[2 * j + 1] - pos[2 * i + 1];  // diff = other - me
     const double dn = std::sqrt(dx * dx + dy * dy);
@@ -577,7 +577,15 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     if (!h->h_agents.empty()) std::memcpy(pb + o_ag, h->h_agents.data(), h->h_agents.size());
     std::memcpy(pb + o_lin, lin, sizeof(double) * nv);
     std::memcpy(pb + o_ang, ang, sizeof(double) * nw);
-    if (rest) rest_forces(h, reinterpret_cast<double *>(pb + o_rest));
+    h->st_rest_pairs.clear();
+    if (rest) {
+      const double *pos = reinterpret_cast<const double *>(h->h_agents.data());
+      const double *vel = reinterpret_cast<const double *>(h->h_agents.data() + h->ao_vel);
+      h->st_rest_pairs = h->rest_pairs;
+      h->st_rest_pv.assign(pos, pos + 2 * h->A);
+      h->st_rest_pv.insert(h->st_rest_pv.end(), vel, vel + 2 * h->A);
+      rest_forces(h->params, h->rest_pairs, pos, vel, h->A, reinterpret_cast<double *>(pb + o_rest));
+    }
     SFW_HIP(h, hipMemcpyAsync(h->world.p, pb, total, hipMemcpyHostToDevice, h->stream));
     SFW_HIP(h, h->pin_world.mark(h->stream));
     const char *db = h->world.p;
@@ -629,8 +637,18 @@ int launch_common(sfw_handle h) {
   SFW_HIP(h, hipSetDevice(h->device));
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
   // sfw_set_params since the stage: tables and shared-prefix plan are redone for the live parameters
-  if (h->plan_epoch != h->params_epoch)
+  if (h->plan_epoch != h->params_epoch) {
     if (int e = plan_tables(h)) return e;
+    if (h->d_agent_rest && !h->st_rest_pairs.empty()) {  // the relative-rest terms depend on the sfm parameters too
+      const size_t bytes = sizeof(double) * 2 * static_cast<size_t>(h->st_A);
+      SFW_HIP(h, h->pin_cls.wait());
+      SFW_HIP(h, h->pin_out.reserve(bytes));
+      rest_forces(h->params, h->st_rest_pairs, h->st_rest_pv.data(), h->st_rest_pv.data() + 2 * h->st_A, h->st_A,
+                  reinterpret_cast<double *>(h->pin_out.p));
+      SFW_HIP(h, hipMemcpyAsync(const_cast<double *>(h->d_agent_rest), h->pin_out.p, bytes, hipMemcpyHostToDevice, h->stream));
+      SFW_HIP(h, hipStreamSynchronize(h->stream));  // pin_out is the fetch buffer too: rare path, keep it simple
+    }
+  }
   const int S = num_steps_of(h->params);
   int64_t chunk = static_cast<int64_t>(std::min(h->rstep.cap, std::min(h->frame.cap, h->fcode.cap)) / S);
   if (chunk > T) chunk = T;

@@ -364,3 +364,27 @@ def test_points_of_a_sample_rejected_by_contact_before_its_illegal_pose(oracle_m
     g.launch()
     gc2, gb2, _ = g.fetch()
     assert np.array_equal(gc, gc2) and gb == gb2
+
+
+def test_set_params_after_stage_refreshes_the_relative_rest_terms(oracle_mod, hip_mod):
+    """The host-evaluated angular terms of pairs at relative rest depend on the lightsfm parameters: changed
+    between stage and launch they must be re-evaluated for the STAGED agents (a later sfw_set_agents only
+    takes effect at the next stage)."""
+    scene, rs = _rest_scene(12, 505, True)
+    p1 = default_params()
+    p2 = default_params(sfm_lambda=1.5, sfm_gamma=0.4, sfm_force_factor_social=3.0)
+    g = hip_mod.HipScorer(p1)
+    g.load_scene(scene)
+    g.stage(rs, scene.linvels, scene.angvels, scene.goal_args)
+    g.set_params(p2)
+    other = syn.make_scene(dataclasses.replace(scene.workload, seed=999))
+    g.set_agents(other.agents, other.obstacles)  # must NOT leak into the launch of the staged grid
+    g.launch()
+    costs, best, _ = g.fetch()
+    o = oracle_mod.OracleScorer(p2)
+    o.load_scene(scene)
+    oc, ob = o.score_grid(rs, scene.linvels, scene.angvels, scene.goal_args, n_threads=8)
+    assert np.array_equal(oc < 0, costs < 0)
+    v = oc >= 0
+    assert np.max(np.abs(costs[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64
+    assert best["index"] == ob["index"]
