@@ -67,6 +67,25 @@ def grouped_scene(seed):
     return sc
 
 
+def standing_scene(seed):
+    """Exact relative rest (round 2): three standing people (v = 0,0 — what a tracker reports for static persons), a
+    standing pair inside a group, two walkers with bit-identical velocities.  lightsfm's sign(theta) for such pairs is the
+    rounding of two atan2; the fixture pins what the oracle (this image's libm) makes of it."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=8, nw=9, n_people=12, seed=seed)
+    sc = syn.make_scene(w)
+    ag = sc.agents
+    for i in (1, 2, 3, 4, 5):
+        ag[i].vx = ag[i].vy = 0.0
+        ag[i].goal_x, ag[i].goal_y = ag[i].x, ag[i].y
+    for i in (4, 5):
+        ag[i].group_id = 7
+    ag[5].x, ag[5].y = ag[4].x + 0.5, ag[4].y + 0.3
+    ag[5].goal_x, ag[5].goal_y = ag[5].x, ag[5].y
+    ag[7].vx, ag[7].vy = ag[6].vx, ag[6].vy
+    ag[7].goal_x, ag[7].goal_y = ag[7].x + 2.0 * ag[7].vx, ag[7].y + 2.0 * ag[7].vy
+    return sc
+
+
 def cases():
     yield "cfg1", syn.make_scene("cfg1"), {}
     for n in (0, 1, 5):
@@ -78,6 +97,7 @@ def cases():
     yield "crowd70_point", syn.make_scene(w), {}
     yield "blocked", blocked_scene(23), {}
     yield "groups_obs", grouped_scene(25), {}
+    yield "standing_people", standing_scene(501), {}
     w = dataclasses.replace(syn.WORKLOADS["cfg3"], nv=5, nw=6, map_size=200, seed=24)
     yield "cfg3_5x6_yamlweights", syn.make_scene(w), dict(social_weight=2.0, vel_weight=0.8, angle_weight=0.6,
                                                           max_vel_x=0.8, robot_radius=0.4)
@@ -85,7 +105,10 @@ def cases():
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    only = set(sys.argv[1:])  # optional: regenerate just the named fixtures
     for name, sc, pkw in cases():
+        if only and name not in only:
+            continue
         w = sc.workload
         p = default_params(sim_time=w.sim_time, sim_granularity=w.sim_granularity, **pkw)
         o = OracleScorer(p)
