@@ -106,3 +106,56 @@ def test_random_scene(oracle_mod, hip_mod, seed):
             assert rel.max() <= 1e4 * sens, f"seed {seed}: max rel err {rel.max():.3e}, oracle response to 2e-14 noise {sens:.3e}"
     assert gb["index"] == ob["index"] and gb["n_valid"] == ob["n_valid"]
     assert gb["vx"] == ob["vx"] and gb["vtheta"] == ob["vtheta"]
+
+
+def _case_standing(seed):
+    """A random scene of the well-conditioned regime (steps of at most 0.05 s) in which a random subset of the people
+    stands still, some walk with bit-identical velocities, some form groups, and the robot is stopped in a third of
+    the cases: pairs at exact relative rest in random geometry."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([2, 3, 5, 9, 20, 31, 50, 64, 90]))
+    steps = int(rng.choice([3, 6, 20, 40]))
+    gran = float(rng.choice([0.025, 0.05]))
+    w = dataclasses.replace(
+        syn.WORKLOADS["cfg2"], nv=int(rng.integers(2, 7)), nw=int(rng.integers(2, 8)), n_people=n,
+        sim_time=steps * gran, sim_granularity=gran, seed=7000 + seed,
+        footprint=str(rng.choice(["point", "polygon16"])), n_obstacles=int(rng.choice([0, 0, 12])))
+    scene = syn.make_scene(w)
+    p = default_params(sim_time=w.sim_time, sim_granularity=gran)
+    ag = scene.agents
+    ids = rng.permutation(np.arange(1, n + 1))
+    n_stand = int(rng.integers(1, max(2, n // 2) + 1))
+    for i in ids[:n_stand]:
+        a = ag[int(i)]
+        a.vx = a.vy = 0.0
+        a.goal_x, a.goal_y = a.x, a.y
+        if rng.random() < 0.3:
+            a.group_id = int(rng.integers(0, 3))
+    rest = [int(i) for i in ids[n_stand:]]
+    for k in range(0, len(rest) - 1, 4):  # a few pairs of walkers share one velocity vector
+        a, b = ag[rest[k]], ag[rest[k + 1]]
+        b.vx, b.vy = a.vx, a.vy
+        b.goal_x, b.goal_y = b.x + 2.0 * b.vx, b.y + 2.0 * b.vy
+    rs = scene.robot_state
+    if seed % 3 == 0:  # a stopped robot: its agent velocity (local twist) is (0, 0) as well
+        rs = (rs[0], rs[1], float(np.float32(rng.uniform(-3, 3))), 0.0, 0.0, 0.0)
+        ag[0].vx = ag[0].vy = 0.0
+    return scene, p, rs, scene.goal_args, scene.linvels, scene.angvels
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_scene_with_pairs_at_relative_rest(oracle_mod, hip_mod, seed):
+    scene, p, rs, ga, lin, ang = _case_standing(seed)
+    o = oracle_mod.OracleScorer(p)
+    o.load_scene(scene)
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    oc, ob = o.score_grid(rs, lin, ang, ga, n_threads=16)
+    gc, gb = g.score_grid(rs, lin, ang, ga)
+    assert np.array_equal(oc < 0, gc < 0) and np.array_equal(oc[oc < 0], gc[gc < 0])
+    v = oc >= 0
+    if v.any():
+        rel = np.abs(gc[v] - oc[v]) / np.maximum(np.abs(oc[v]), 1e-300)
+        assert rel.max() <= 1e-9, f"seed {seed}: max rel err {rel.max():.3e}"
+    assert gb["index"] == ob["index"] and gb["n_valid"] == ob["n_valid"]
+    assert gb["vx"] == ob["vx"] and gb["vtheta"] == ob["vtheta"]
