@@ -281,16 +281,37 @@ __global__ void __launch_bounds__(256) sfw_costmap_scan_kernel(const sfw_launch 
   scan_finish(L, t, local, cm, n_ok);
 }
 
-// K1 for small grids (a control cycle of the reference's own 5 x 9 samples): the three stages in
-// one launch, one 64-thread block per sample.  Lane 0 integrates the poses into LDS, the block's
-// lanes check one step's footprint each, lane 0 scans the codes in step order.  Same device
-// functions, same arithmetic, two kernel boundaries fewer on the latency path.
+// One footprint edge of a pose: the largest cell value on edge e (vertex e -> vertex e+1, the last edge closes the
+// polygon), or FOOT_OFFMAP when one of its vertices is off the map.  The same expressions as footprint_cost.
+constexpr int FOOT_OFFMAP = 300;
+__device__ __forceinline__ int footprint_edge(const sfw_launch &L, double x, double y, double c, double s, int e) {
+  const double inv_res = 1.0 / L.resolution;
+  const int e1 = (e + 1 < L.K) ? e + 1 : 0;
+  const double ax = L.footprint[2 * e], ay = L.footprint[2 * e + 1], bx = L.footprint[2 * e1], by = L.footprint[2 * e1 + 1];
+  unsigned x0, y0, x1, y1;
+  if (!world_to_map(L, inv_res, x + (ax * c - ay * s), y + (ax * s + ay * c), x0, y0)) return FOOT_OFFMAP;
+  if (!world_to_map(L, inv_res, x + (bx * c - by * s), y + (bx * s + by * c), x1, y1)) return FOOT_OFFMAP;
+  return line_max(L, (int)x0, (int)y0, (int)x1, (int)y1);
+}
+
+// K1 for small grids (a control cycle of the reference's own 5 x 9 samples): the three stages in one launch, one
+// 64-thread block per sample, two kernel boundaries fewer on the latency path.  A single wave is latency-bound, so
+// everything that is not a true recurrence runs across the lanes:
+//   (1) the three velocity recurrences (computeNewVelocity, ref :581-583) on lanes 0, 1, 2, the heading sum with the
+//       angular one (ref :588);
+//   (2) one step per lane: sincos of the heading, the position increments (vx cos + vy cos(pi/2 + th)) dt (ref :586-587);
+//   (3) the two position sums x += dx_i, y += dy_i on lanes 0 and 1 — 40 dependent adds each instead of 40 whole steps;
+//   (4) one step per lane: robot-step records, Trajectory points; lane 0: the pedestrian-free cost terms;
+//   (5) one (pose, footprint edge) per lane, combined per pose with an LDS max; (6) lane 0 scans the codes in step order.
+// The same operations on the same values in the same order as the one-thread-per-sample K1a + K1b + K1c (no
+// contraction here either): bit-identical poses, cells, codes and costs.
 constexpr int K1_SMALL_MAX_STEPS = 512;
 __global__ void __launch_bounds__(64) sfw_rollout_small_kernel(const sfw_launch L) {
-  __shared__ sfw_pose_frame fr[K1_SMALL_MAX_STEPS];
   __shared__ double th[K1_SMALL_MAX_STEPS], vxs[K1_SMALL_MAX_STEPS], vys[K1_SMALL_MAX_STEPS];
-  __shared__ double2 cs[K1_SMALL_MAX_STEPS], cs2[K1_SMALL_MAX_STEPS];
-  __shared__ int16_t code[K1_SMALL_MAX_STEPS];
+  __shared__ double2 cs[K1_SMALL_MAX_STEPS], dxy[K1_SMALL_MAX_STEPS];
+  __shared__ double xs[K1_SMALL_MAX_STEPS + 1], ys[K1_SMALL_MAX_STEPS + 1];
+  __shared__ int code[K1_SMALL_MAX_STEPS];
+  __shared__ double th_end;
   const int64_t local = blockIdx.x;
   const int64_t t = L.chunk_begin + local;
   const int S = L.S;
@@ -298,12 +319,9 @@ __global__ void __launch_bounds__(64) sfw_rollout_small_kernel(const sfw_launch 
   const double vx_samp = L.linvels[iv], vth_samp = L.angvels[iw], vy_samp = L.vy_samp;
   const bool scored = !(L.skip_zero_sample && vx_samp == 0.0 && vth_samp == 0.0);
   const double dt = L.dt;
-  // rollout_sample's recurrence, split so that its only expensive part — one sincos per step, i.e.
-  // S dependent ~1000-cycle calls on one lane — runs on the block's 64 lanes at once: the velocity
-  // and heading recurrences do not depend on the sines, the position recurrence only adds them up.
-  // Same operations on the same values in the same order as the one-thread-per-sample K1a.
-  double th_i = L.rs.theta;
-  if (threadIdx.x == 0) {  // stage 1: velocities and headings, a few flops per step
+  const int tid = threadIdx.x;
+  // (1) velocities and headings
+  if (tid == 0) {
     if (!scored) {
       L.status[t] = SFW_ST_SKIPPED;
       L.costs[t] = SFW_COST_SKIPPED;
@@ -311,69 +329,93 @@ __global__ void __launch_bounds__(64) sfw_rollout_small_kernel(const sfw_launch 
       L.status[t] = SFW_ST_VALID;  // the costmap scan downgrades it if a step is illegal
     }
     if (L.coll_step) L.coll_step[t] = -1;
-    double vx_i = L.rs.vx, vy_i = L.rs.vy, vth_i = L.rs.vtheta;
+    double v = L.rs.vx;
+    for (int i = 0; i < S; ++i) vxs[i] = v = new_velocity(vx_samp, v, L.ga.acc_x, dt);   // ref :581
+  } else if (tid == 1) {
+    double v = L.rs.vy;
+    for (int i = 0; i < S; ++i) vys[i] = v = new_velocity(vy_samp, v, L.ga.acc_y, dt);   // ref :582
+  } else if (tid == 2) {
+    double v = L.rs.vtheta, th_i = L.rs.theta;
     for (int i = 0; i < S; ++i) {
-      vx_i = new_velocity(vx_samp, vx_i, L.ga.acc_x, dt);   // ref :581-583
-      vy_i = new_velocity(vy_samp, vy_i, L.ga.acc_y, dt);
-      vth_i = new_velocity(vth_samp, vth_i, L.ga.acc_theta, dt);
+      v = new_velocity(vth_samp, v, L.ga.acc_theta, dt);                                // ref :583
       th[i] = th_i;  // heading before this step's update: ref :586-588 integrate with the old theta
-      vxs[i] = vx_i;
-      vys[i] = vy_i;
-      th_i = th_i + vth_i * dt;
+      th_i = th_i + v * dt;
     }
+    th_end = th_i;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < S; i += blockDim.x) {  // stage 2: the sines, one step per lane
+  // (2) sines and position increments, one step per lane
+  for (int i = tid; i < S; i += blockDim.x) {
     double s, c, c2 = 0.0, s2 = 0.0;
     sincos(th[i], &s, &c);
     if (vys[i] != 0.0) sincos(M_PI_2 + th[i], &s2, &c2);  // holonomic term, 0 for the grid
     cs[i] = double2{c, s};
-    cs2[i] = double2{c2, s2};
+    dxy[i] = double2{(vxs[i] * c + vys[i] * c2) * dt, (vxs[i] * s + vys[i] * s2) * dt};  // ref :586-587
+    code[i] = 0;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {  // stage 3: positions, robot-step records, pedestrian-free cost terms
-    double x_i = L.rs.x, y_i = L.rs.y, vx_i = L.rs.vx;
-    for (int i = 0; i < S; ++i) {
-      const double2 a = cs[i], b = cs2[i];
-      sfw_pose_frame f;
-      f.x = x_i; f.y = y_i; f.c = a.x; f.s = a.y;
-      fr[i] = f;
-      if (L.points) {                                       // ref :578
-        double *pt = L.points + (local * S + i) * 3;
-        pt[0] = x_i;
-        pt[1] = y_i;
-        pt[2] = th[i];
-      }
-      vx_i = vxs[i];
-      const double vy_i = vys[i];
-      const double xn = x_i + (vx_i * a.x + vy_i * b.x) * dt;  // ref :586-588
-      const double yn = y_i + (vx_i * a.y + vy_i * b.y) * dt;
-      x_i = xn;
-      y_i = yn;
-      sfw_robot_step r;
-      r.x = x_i; r.y = y_i; r.vx = vx_i; r.vy = vy_i;
-      L.rstep[static_cast<int64_t>(i) * L.rstep_stride + local] = r;
+  // (3) positions: xs[i] = pose before step i, xs[S] = final pose
+  if (tid == 0) {
+    double x = L.rs.x;
+    xs[0] = x;
+    for (int i = 0; i < S; ++i) xs[i + 1] = x = x + dxy[i].x;
+  } else if (tid == 1) {
+    double y = L.rs.y;
+    ys[0] = y;
+    for (int i = 0; i < S; ++i) ys[i + 1] = y = y + dxy[i].y;
+  }
+  __syncthreads();
+  // (4) records, one step per lane
+  for (int i = tid; i < S; i += blockDim.x) {
+    if (L.points) {                                        // ref :578
+      double *pt = L.points + (local * S + i) * 3;
+      pt[0] = xs[i];
+      pt[1] = ys[i];
+      pt[2] = th[i];
     }
+    sfw_robot_step r;
+    r.x = xs[i + 1]; r.y = ys[i + 1]; r.vx = vxs[i]; r.vy = vys[i];
+    L.rstep[static_cast<int64_t>(i) * L.rstep_stride + local] = r;
+  }
+  if (tid == 0) {
     // ref :643-666 without the costmap and social terms (left-to-right sum order kept)
-    const double dx = L.ga.wpx - x_i, dy = L.ga.wpy - y_i;
+    const double dx = L.ga.wpx - xs[S], dy = L.ga.wpy - ys[S];
     const double d = dx * dx + dy * dy;
-    double ang = atan2(dy, dx) - th_i;
+    double ang = atan2(dy, dx) - th_end;
     ang = normalize_angle_f(static_cast<float>(ang), static_cast<float>(-M_PI), static_cast<float>(M_PI));
     ang = fabs(ang) / M_PI;
-    const double vel = fabs(L.p.max_vel_x - vx_i) / L.p.max_vel_x;
+    const double vel = fabs(L.p.max_vel_x - vxs[S - 1]) / L.p.max_vel_x;
     L.base_cost[t] = L.p.vel_weight * vel + L.p.distance_weight * d + L.p.angle_weight * ang;
   }
-  __syncthreads();
   if (!scored) {
-    if (threadIdx.x == 0 && L.n_points) L.n_points[local] = 0;
+    if (tid == 0 && L.n_points) L.n_points[local] = 0;
     return;
   }
-  for (int i = threadIdx.x; i < S; i += blockDim.x) {
-    const sfw_pose_frame f = fr[i];
-    code[i] = static_cast<int16_t>(footprint_cost(L, f.x, f.y, f.c, f.s));  // includes the ref :545 map check
+  // (5) footprint: the pose centre must be on the map (ref :545, src/costmap_model.cpp:36-37); K < 3: centre cell
+  // only; else every (pose, edge) is a task of its own and a pose's code is the maximum over its tasks
+  const int K = L.K;
+  if (K < 3) {
+    for (int i = tid; i < S; i += blockDim.x) {
+      const double2 a = cs[i];
+      const double fc = footprint_cost(L, xs[i], ys[i], a.x, a.y);
+      code[i] = fc < 0 ? FOOT_OFFMAP : static_cast<int>(fc);
+    }
+  } else {
+    const double inv_res = 1.0 / L.resolution;
+    for (int task = tid; task < S * K; task += blockDim.x) {
+      const int i = task / K, e = task - i * K;
+      const double2 a = cs[i];
+      int v = footprint_edge(L, xs[i], ys[i], a.x, a.y, e);
+      if (e == 0) {
+        unsigned cx, cy;
+        if (!world_to_map(L, inv_res, xs[i], ys[i], cx, cy)) v = FOOT_OFFMAP;
+      }
+      atomicMax(&code[i], v);
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  // (6) in-order scan
+  if (tid == 0) {
     double cm = 0.0;
     int n_ok = 0;
     for (int i = 0; i < S; ++i)
