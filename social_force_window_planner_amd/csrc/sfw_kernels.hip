@@ -295,7 +295,7 @@ __device__ __forceinline__ int footprint_edge(const sfw_launch &L, double x, dou
 }
 
 // K1 for small grids (a control cycle of the reference's own 5 x 9 samples): the three stages in one launch, one
-// 64-thread block per sample, two kernel boundaries fewer on the latency path.  A single wave is latency-bound, so
+// 256-thread block per sample, two kernel boundaries fewer on the latency path.  A single wave is latency-bound, so
 // everything that is not a true recurrence runs across the lanes:
 //   (1) the three velocity recurrences (computeNewVelocity, ref :581-583) on lanes 0, 1, 2, the heading sum with the
 //       angular one (ref :588);
@@ -306,7 +306,8 @@ __device__ __forceinline__ int footprint_edge(const sfw_launch &L, double x, dou
 // The same operations on the same values in the same order as the one-thread-per-sample K1a + K1b + K1c (no
 // contraction here either): bit-identical poses, cells, codes and costs.
 constexpr int K1_SMALL_MAX_STEPS = 512;
-__global__ void __launch_bounds__(64) sfw_rollout_small_kernel(const sfw_launch L) {
+constexpr int K1_SMALL_BLOCK = 256;  // four waves per sample: the (pose, edge) footprint tasks are the bulk of the work
+__global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const sfw_launch L) {
   __shared__ double th[K1_SMALL_MAX_STEPS], vxs[K1_SMALL_MAX_STEPS], vys[K1_SMALL_MAX_STEPS];
   __shared__ double2 cs[K1_SMALL_MAX_STEPS], dxy[K1_SMALL_MAX_STEPS];
   __shared__ double xs[K1_SMALL_MAX_STEPS + 1], ys[K1_SMALL_MAX_STEPS + 1];
@@ -1716,7 +1717,7 @@ bool sfw_rollout_is_fused(const sfw_launch &L) { return L.chunk_count <= 2048 &&
 hipError_t sfw_launch_rollout_poses(const sfw_launch &L, hipStream_t stream) {
   if (L.chunk_count <= 0) return hipSuccess;
   if (sfw_rollout_is_fused(L)) {  // latency path: one launch does all of K1
-    hipLaunchKernelGGL(sfw_rollout_small_kernel, dim3(static_cast<unsigned>(L.chunk_count)), dim3(64), 0, stream, L);
+    hipLaunchKernelGGL(sfw_rollout_small_kernel, dim3(static_cast<unsigned>(L.chunk_count)), dim3(K1_SMALL_BLOCK), 0, stream, L);
     return hipGetLastError();
   }
   const int block = 64;  // latency-bound serial rollout: spread the waves over all CUs
