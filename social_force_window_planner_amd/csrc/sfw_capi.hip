@@ -1291,6 +1291,15 @@ struct sfw_multi_s {
   std::string err;
 };
 
+#define SFW_MHIP(m, h, call)                                                                  \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (m)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+      return hip_fail((h), e_, #call);                                                        \
+    }                                                                                         \
+  } while (0)
+
 namespace {
 int mfail(sfw_multi_handle m, int code, const std::string &msg) {
   if (m) m->err = msg;
@@ -1422,7 +1431,7 @@ int sfw_multi_score_grid(sfw_multi_handle m, const sfw_robot_state *rs, const do
   for (int r = 0; r < R; ++r) {
     sfw_handle h = m->h[static_cast<size_t>(r)];
     const int32_t lo = m->row0[static_cast<size_t>(r)], n = m->row0[static_cast<size_t>(r) + 1] - lo;
-    SFW_HIP(h, hipSetDevice(m->dev[static_cast<size_t>(r)]));
+    SFW_MHIP(m, h, hipSetDevice(m->dev[static_cast<size_t>(r)]));
     if (n > 0) {
       if (int e = sfw_grid_stage(h, rs, linvels + lo, n, angvels, nw, args, static_cast<int64_t>(lo) * nw))
         return mrank_fail(m, r, e, "sfw_grid_stage");
@@ -1451,20 +1460,20 @@ int sfw_multi_score_grid(sfw_multi_handle m, const sfw_robot_state *rs, const do
     if (nr == ncclSuccess) nr = ne;
     if (nr != ncclSuccess) return mfail(m, SFW_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nr));
     sfw_handle h0 = m->h[0];
-    SFW_HIP(h0, hipSetDevice(m->dev[0]));
-    SFW_HIP(h0, hipMemcpyAsync(m->pin_table, m->d_table[0], sizeof(double) * 5 * R, hipMemcpyDeviceToHost, h0->stream));
-    SFW_HIP(h0, hipStreamSynchronize(h0->stream));
+    SFW_MHIP(m, h0, hipSetDevice(m->dev[0]));
+    SFW_MHIP(m, h0, hipMemcpyAsync(m->pin_table, m->d_table[0], sizeof(double) * 5 * R, hipMemcpyDeviceToHost, h0->stream));
+    SFW_MHIP(m, h0, hipStreamSynchronize(h0->stream));
   } else {  // host reduce: each rank's own row
     for (int r = 0; r < R; ++r) {
       sfw_handle h = m->h[static_cast<size_t>(r)];
-      SFW_HIP(h, hipSetDevice(m->dev[static_cast<size_t>(r)]));
-      SFW_HIP(h, hipMemcpyAsync(m->pin_table + 5 * r, m->d_table[static_cast<size_t>(r)] + 5 * r, sizeof(double) * 5,
+      SFW_MHIP(m, h, hipSetDevice(m->dev[static_cast<size_t>(r)]));
+      SFW_MHIP(m, h, hipMemcpyAsync(m->pin_table + 5 * r, m->d_table[static_cast<size_t>(r)] + 5 * r, sizeof(double) * 5,
                                 hipMemcpyDeviceToHost, h->stream));
     }
     for (int r = 0; r < R; ++r) {
       sfw_handle h = m->h[static_cast<size_t>(r)];
-      SFW_HIP(h, hipSetDevice(m->dev[static_cast<size_t>(r)]));
-      SFW_HIP(h, hipStreamSynchronize(h->stream));
+      SFW_MHIP(m, h, hipSetDevice(m->dev[static_cast<size_t>(r)]));
+      SFW_MHIP(m, h, hipStreamSynchronize(h->stream));
     }
   }
   const double t2 = now_us();

@@ -854,6 +854,9 @@ template <bool GROUPS, bool CONSTS>
 __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout &s, int lane, int G, int Gn,
                                            int64_t first_local) {
   const int A = L.A, O = L.O;
+  // lds_at() takes offsets into the wave's allocation for LDS addresses: true only while the K2 kernels have no
+  // static __shared__ data in front of the dynamic allocation (s.px is the allocation's first byte)
+  if (static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char *)(s.px))) != 0u) __builtin_trap();
   if constexpr (CONSTS) {
     for (int i = lane; i < A; i += WAVE) {
       const sfw_agent_const c = L.agent_c[i];
