@@ -54,6 +54,8 @@ def lib():
         L.sfwh_trajectory_points.argtypes = [vp, C.c_int64, vp, C.c_int32]
         L.sfwh_all_trajectories.argtypes = [vp, vp, C.c_int32, vp]
         L.sfwh_all_trajectories.restype = C.c_int64
+        L.sfwh_markers.argtypes = [vp, vp, vp, vp]
+        L.sfwh_markers.restype = C.c_int64
         L.sfwh_get_yaw.argtypes = [C.c_double] * 4
         L.sfwh_get_yaw.restype = C.c_double
         _lib = L
@@ -106,6 +108,14 @@ class HostPlanner:
         cells = np.ascontiguousarray(cells, dtype=np.uint8)
         sy, sx = cells.shape
         lib().sfwh_set_costmap(self._h, cells.ctypes.data, sx, sy, ox, oy, res)
+
+    def markers(self, n_samples):
+        """SFWPlanner::getMarkers: (rgba[T,4], point counts[T], z of the first point[T]) or None."""
+        rgba = np.zeros((n_samples, 4), dtype=np.float32)
+        counts = np.zeros(n_samples, dtype=np.int32)
+        z0 = np.zeros(n_samples, dtype=np.float64)
+        n = lib().sfwh_markers(self._h, rgba.ctypes.data, counts.ctypes.data, z0.ctypes.data)
+        return None if n < 0 else (rgba, counts, z0)
 
     def set_devices(self, devices, host_reduce=False):
         """SFWPlanner::setDevices: grid rows over several devices from this process (before the first scoring call)."""

@@ -239,6 +239,32 @@ geometry_msgs::msg::TwistStamped SFWPlannerNode::computeVelocityCommands(const g
   in_speed.linear = Vector3{speed.linear.x, speed.linear.y, 0.0};
   in_speed.angular.z = speed.angular.z;
   const bool ok = sfw_planner_->findBestAction(toPod(robot_pose), in_speed, cmd);  // ref :281
+  // ref :283, :301-309: the trajectory markers go out on both exits (red rejected, blue valid, green selected)
+  std::vector<SFWPlanner::MarkerData> md;
+  if (sfw_planner_->getMarkers(md)) {
+    visualization_msgs::msg::MarkerArray markers;
+    const auto stamp = node_->get_clock()->now();
+    for (const SFWPlanner::MarkerData &d : md) {
+      visualization_msgs::msg::Marker m;               // ref src/sfw_planner.cpp:92-106
+      m.header.frame_id = sfw_planner_->params().controller_frame_;
+      m.header.stamp = stamp;
+      m.ns = "trajectories";
+      m.id = d.id;
+      m.type = 4;                                      // LINE_STRIP
+      m.action = 0;
+      m.lifetime = rclcpp::Duration::from_seconds(0.3);
+      m.scale.x = 0.01;
+      m.color.r = d.r; m.color.g = d.g; m.color.b = d.b; m.color.a = d.a;
+      m.pose.orientation.w = 1.0;
+      for (const Point &q : d.points) {
+        geometry_msgs::msg::Point gp;
+        gp.x = q.x; gp.y = q.y; gp.z = q.z;
+        m.points.push_back(gp);
+      }
+      markers.markers.push_back(m);
+    }
+    traj_pub_->publish(markers);
+  }
   if (!ok) return vel;                               // ref :295-304: zero TwistStamped
   vel.header.stamp = node_->get_clock()->now();
   vel.header.frame_id = gframe;

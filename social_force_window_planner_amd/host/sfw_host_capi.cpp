@@ -201,6 +201,19 @@ int64_t sfwh_all_trajectories(void *hv, double *xyth, int32_t cap, int32_t *coun
   }
   return static_cast<int64_t>(ts.size());
 }
+// markers of the last cycle: rgba = T x 4 floats, counts = T point counts, z0 = T z of each marker's first point (0 if none);
+// returns T, or -1 when the cycle left the markers untouched
+int64_t sfwh_markers(void *hv, float *rgba, int32_t *counts, double *z0) {
+  HostHandle *h = static_cast<HostHandle *>(hv);
+  std::vector<SFWPlanner::MarkerData> ms;
+  if (!h->planner->getMarkers(ms)) return -1;
+  for (size_t i = 0; i < ms.size(); ++i) {
+    rgba[4 * i] = ms[i].r; rgba[4 * i + 1] = ms[i].g; rgba[4 * i + 2] = ms[i].b; rgba[4 * i + 3] = ms[i].a;
+    counts[i] = static_cast<int32_t>(ms[i].points.size());
+    z0[i] = ms[i].points.empty() ? 0.0 : ms[i].points[0].z;
+  }
+  return static_cast<int64_t>(ms.size());
+}
 double sfwh_get_yaw(double x, double y, double z, double w) { return getYaw(Quaternion{x, y, z, w}); }
 }
 

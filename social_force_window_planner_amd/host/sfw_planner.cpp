@@ -289,6 +289,7 @@ bool SFWPlanner::findBestAction(const PoseStamped &global_pose, const Twist &glo
     if (scoreTrajectory(rx, ry, rt, rvx, rvy, rvt, vx, vy, vt, params_.max_trans_acc_, 0.0,
                         params_.max_rot_acc_, wpx, wpy, agents, t) != -1) {
       last_branch_ = kApproach;
+      last_approach_traj_ = t;
       setCmd(cmd_vel, vx, vy, vt);
       return true;
     }
@@ -362,6 +363,39 @@ bool SFWPlanner::getTrajectories(std::vector<Trajectory> &out) {
     t.cost_ = last_costs_[static_cast<size_t>(i)];
     const double *p = pts.data() + static_cast<size_t>(i) * 3 * S;
     for (int k = 0; k < n[static_cast<size_t>(i)]; ++k) t.addPoint(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+  }
+  return true;
+}
+
+bool SFWPlanner::getMarkers(std::vector<MarkerData> &out) {
+  const size_t T = linvels_.size() * angvels_.size();
+  auto fill = [](MarkerData &m, const Trajectory &t, double z) {
+    for (unsigned k = 0; k < t.getPointsSize(); ++k) {
+      double x, y, th;
+      t.getPoint(k, x, y, th);
+      m.points.push_back(Point{x, y, z});
+    }
+  };
+  if (last_branch_ == kApproach) {  // ref :309-325
+    out.assign(T, MarkerData());
+    for (size_t i = 0; i < T; ++i) out[i].id = static_cast<int>(i);
+    fill(out[0], last_approach_traj_, 0.0);
+    out[0].r = 0.0f; out[0].g = 1.0f; out[0].b = 0.0f; out[0].a = 1.0f;
+    return true;
+  }
+  if (last_branch_ != kGrid && last_branch_ != kGridFailed) return false;
+  std::vector<Trajectory> ts;
+  if (!getTrajectories(ts)) return false;
+  out.assign(T, MarkerData());
+  for (size_t i = 0; i < T; ++i) {
+    MarkerData &m = out[i];
+    m.id = static_cast<int>(i);
+    if (ts[i].xv_ == 0.0 && ts[i].thetav_ == 0.0) continue;  // ref :349-352: cleared, never scored
+    const bool best = last_branch_ == kGrid && static_cast<int64_t>(i) == last_best_.index;
+    fill(m, ts[i], best ? 0.1 : 0.0);                         // ref :366-374, :435-437
+    if (best) { m.r = 0.0f; m.g = 1.0f; m.b = 0.0f; m.a = 1.0f; }          // ref :438-441
+    else if (ts[i].cost_ < 0.0) { m.r = 1.0f; m.g = 0.0f; m.b = 0.0f; m.a = 0.6f; }  // ref :376-380
+    else { m.r = 0.0f; m.g = 0.0f; m.b = 1.0f; m.a = 0.6f; }              // ref :381-385
   }
   return true;
 }

@@ -148,6 +148,19 @@ class SFWPlanner {
   // after the loop (:347-386): points of every scored sample, cost_ < 0 for rejected ones
   // (drawn red there), the winner is lastBest().index (drawn green).
   bool getTrajectories(std::vector<Trajectory> &out);
+  // What the reference's MarkerArray holds after this cycle (getMarkers(), src/sfw_planner.cpp:86-113): one LINE_STRIP
+  // marker per sample (ns "trajectories", id = iteration index, scale.x 0.01, lifetime 0.3 s, pose.orientation.w 1).
+  // Grid branch (:347-386, :435-440): points of every scored sample at z = 0, red (1,0,0,0.6) when its cost is < 0, blue
+  // (0,0,1,0.6) otherwise; the selected sample green (0,1,0,1) with its points raised to z = 0.1; the never-scored (0,0)
+  // sample empty.  Approach branch (:309-325): marker 0 = the approach trajectory, green.  (The reference means to clear
+  // the other markers there but iterates over copies, `for (auto m : markers_.markers)`, so they keep last cycle's points;
+  // here they are cleared, as intended.)  false: the cycle took a branch that leaves the markers untouched.
+  struct MarkerData {
+    int id = 0;
+    float r = 0, g = 0, b = 0, a = 1;
+    std::vector<Point> points;
+  };
+  bool getMarkers(std::vector<MarkerData> &out);
   int wpIndex() const { return wp_index_; }
   bool running() const { return running_; }
 
@@ -169,6 +182,7 @@ class SFWPlanner {
   bool host_reduce_ = false;
   int device_ = 0;
   std::vector<double> last_costs_;
+  Trajectory last_approach_traj_;
   sfw_best last_best_{};
   int last_branch_ = kNotRunning;
   bool grid_staged_ = false;

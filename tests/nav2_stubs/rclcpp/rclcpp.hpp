@@ -13,6 +13,11 @@ class Time {
   double seconds() const { return 0.0; }
   operator builtin_interfaces::msg::Time() const { return builtin_interfaces::msg::Time(); }
 };
+class Duration {
+ public:
+  static Duration from_seconds(double) { return Duration(); }
+  template <class D> operator D() const { return D(); }  // -> builtin_interfaces::msg::Duration
+};
 class Clock { public: using SharedPtr = std::shared_ptr<Clock>; Time now() const { return Time(); } };
 class ParameterValue {
  public:

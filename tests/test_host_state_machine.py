@@ -194,3 +194,52 @@ def test_non_circular_rotation_check(oracle_mod, host_built):
     ro, rh = o.find_best_action([0, 0, 0], [0, 0, 0]), h.find_best_action([0, 0, 0], [0, 0, 0])
     _same(ro, rh)
     assert ro[0] is False and ro[2] == BRANCH_ROTATE_BLOCKED and ro[1].tolist() == [0.0, 0.0, 0.3]
+
+
+@pytest.mark.gpu
+def test_marker_data_of_every_branch(oracle_mod, host_built):
+    """SFWPlanner::getMarkers = what the reference's MarkerArray holds after a cycle (ref src/sfw_planner.cpp:86-113,
+    :309-325, :347-386, :435-440): red rejected / blue valid / green selected with raised points, the (0,0) sample
+    empty; the approach trajectory as marker 0; untouched by the branches that do not score."""
+    scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["ref5x9"], n_people=3, seed=91))
+    cells = scene.cells.copy()
+    cells[:] = 0
+    cells[:, 118:121] = 254  # a wall 0.9 m ahead: the fast straight samples are rejected, the slow / turning ones not
+    scene.cells[:] = cells
+    o, h = _pair(oracle_mod, host_built, scene)
+    assert h.markers(45) is None  # not running: markers untouched
+    for pl in (o, h):
+        pl.update_plan([[x, 0.1 * x, 0.0] for x in np.linspace(0.0, 4.0, 17)])
+    ro, rh = o.find_best_action([0, 0, 0], [0.3, 0, 0]), h.find_best_action([0, 0, 0], [0.3, 0, 0])
+    _same(ro, rh)
+    assert ro[2] == BRANCH_GRID
+    rgba, counts, z0 = h.markers(45)
+    costs = h.last_costs()
+    best = int(np.flatnonzero((rgba == [0, 1, 0, 1]).all(axis=1))[0])
+    assert counts[0] == 0                                          # the never-scored (0,0) sample
+    assert (rgba == [0, 1, 0, 1]).all(axis=1).sum() == 1 and z0[best] == 0.1 and costs[best] >= 0
+    lin, ang = syn.reference_sampler()
+    assert (lin[best // 9], ang[best % 9]) == (rh[1][0], rh[1][2])   # the green marker is the command
+    rej = np.flatnonzero(costs == -1.0)
+    assert len(rej) > 0 and np.allclose(rgba[rej], [1, 0, 0, 0.6]) and (z0[rej] == 0).all()
+    val = np.setdiff1d(np.flatnonzero(costs >= 0), [best])
+    assert len(val) > 0 and np.allclose(rgba[val], [0, 0, 1, 0.6]) and (counts[val] == 40).all()
+    allp, cnt = h.all_trajectories(45, 40)
+    assert np.array_equal(cnt, counts)
+    # every sample rejected: no green marker, 44 red ones
+    cells[:] = 254
+    for pl in (o, h):
+        pl.set_costmap(cells, scene.origin_x, scene.origin_y, scene.resolution)
+    rh = h.find_best_action([0, 0, 0], [0.3, 0, 0])
+    assert rh[0] is False and rh[2] == BRANCH_GRID_FAILED
+    rgba, counts, _ = h.markers(45)
+    assert np.allclose(rgba[1:], [1, 0, 0, 0.6]) and counts[0] == 0
+    # approach branch: marker 0 = the approach trajectory in green, the others empty
+    cells[:] = 0
+    h2 = host_built.HostPlanner(default_ctrl_params(), scene)
+    h2.set_costmap(cells, scene.origin_x, scene.origin_y, scene.resolution)
+    h2.update_plan([[0, 0, 0], [0.5, 0.2, 0.0], [1.0, 0.4, 0.0]])
+    r2 = h2.find_best_action([0, 0, 0], [0.3, 0, 0])
+    assert r2[2] == BRANCH_APPROACH
+    rgba, counts, z0 = h2.markers(45)
+    assert np.allclose(rgba[0], [0, 1, 0, 1]) and counts[0] == 40 and (counts[1:] == 0).all() and z0[0] == 0.0
