@@ -176,12 +176,13 @@ def run_config(workload_name, precision, steps, warmup, ctx, scaling="weak", res
     from social_force_window_planner_amd import multi_gpu
 
     state = {"win": (0, None), "xchg": []}
+    exchange = multi_gpu.KeyExchange(dist, rank, world, device=ctx["coll_device"]) if dist is not None else None
 
     def one_step():
         _, best, key = job.step(resident)
         if dist is not None:  # single all-reduce(min): every rank fills its own row, +inf elsewhere
             t0 = time.perf_counter()
-            wr, wk, _ = multi_gpu.exchange_best(key, dist, rank, world, device=ctx["coll_device"])
+            wr, wk, _ = exchange(key)
             state["xchg"].append(time.perf_counter() - t0)
             state["win"] = (wr, wk)
         return best, key

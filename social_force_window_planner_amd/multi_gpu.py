@@ -65,6 +65,30 @@ def exchange_best(local_key, dist, rank: int, world: int, device=None):
     return win_rank, win_key, table
 
 
+class KeyExchange:
+    """exchange_best with its tensors allocated once (a bench step is ~10 ms, the exchange should stay in the
+    tens of microseconds): the [world,4] table on `device`, a host staging row, one all-reduce(min) per call."""
+
+    def __init__(self, dist, rank: int, world: int, device=None):
+        import torch
+
+        self.dist, self.rank, self.world = dist, rank, world
+        self.table = torch.full((world, 4), INF, dtype=torch.float64, device=device)
+        on_gpu = self.table.is_cuda
+        self.row = torch.empty(4, dtype=torch.float64, pin_memory=on_gpu)
+        self.host = torch.empty((world, 4), dtype=torch.float64, pin_memory=on_gpu)
+
+    def __call__(self, local_key):
+        self.row[0], self.row[1], self.row[2], self.row[3] = (float(v) for v in local_key)
+        self.table.fill_(INF)
+        self.table[self.rank].copy_(self.row, non_blocking=True)
+        self.dist.all_reduce(self.table, op=self.dist.ReduceOp.MIN)
+        self.host.copy_(self.table)  # synchronises
+        table = self.host.numpy()
+        win_rank, win_key = lexicographic_min(table)
+        return win_rank, win_key, table
+
+
 def cmd_from_key(key, nw_total: int, linvels_all, angvels):
     """Global (vx, vtheta, index) from a winning key; (0, 0, -1) when none."""
     if key is None:

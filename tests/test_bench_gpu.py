@@ -93,6 +93,10 @@ r, k, table = multi_gpu.exchange_best(key, dist, 0, 1, device="cuda:0")
 assert r == 0 and k == key and table.shape == (1, 4), (r, k, table)
 r, k, _ = multi_gpu.exchange_best((float("inf"),) * 4, dist, 0, 1, device="cuda:0")
 assert r is None and k is None
+ex = multi_gpu.KeyExchange(dist, 0, 1, device="cuda:0")
+for _ in range(3):
+    r, k, table = ex(key)
+    assert r == 0 and k == key and table.shape == (1, 4), (r, k, table)
 t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
 dist.destroy_process_group()
 print("rccl-ok")

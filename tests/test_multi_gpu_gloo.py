@@ -50,6 +50,11 @@ def _worker(rank, world, port, wl, out_dir, tie):
             costs = np.zeros(0)
             key = (multi_gpu.INF,) * 4
         win_rank, win_key, table = multi_gpu.exchange_best(key, dist, rank, world)
+        # the preallocated form bench.py uses gives the same table, call after call
+        ex = multi_gpu.KeyExchange(dist, rank, world)
+        for _ in range(2):
+            r2, k2, t2 = ex(key)
+            assert r2 == win_rank and k2 == win_key and np.array_equal(t2, table)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), costs=costs, lo=lo, hi=hi, win_rank=-1 if win_rank is None else win_rank,
                  win_key=np.array(win_key if win_key else (np.inf,) * 4), table=table)
     finally:
