@@ -231,11 +231,17 @@ int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out,
  * of the last level (`classes` of them).  Costs are bit-identical to the
  * plain rollout; SFW_PREFIX=0 in the environment of sfw_create switches it
  * off, SFW_PREFIX=3,7,12 forces the levels' end steps. */
+#define SFW_ORG_NONE 0       /* no agents: the social-force kernel is not launched             */
+#define SFW_ORG_REGISTER_1 1 /* register-resident, one agent slot per lane (A <= 64, floor(64/A) samples per wave) */
+#define SFW_ORG_REGISTER_2 2 /* register-resident, two agent slots per lane (64 < A <= 128)      */
+#define SFW_ORG_FLAT 3       /* all unordered pairs flattened over the lanes, one sample per wave */
 typedef struct sfw_plan_info {
   int32_t split_step;  /* last shared step + 1; 0: plain rollout             */
   int32_t levels;
   int32_t chunks;      /* launches of the K1->K2 table (SFW_TABLE_BUDGET_MB) */
-  int32_t reserved;
+  int32_t organisation; /* SFW_ORG_*: how a wave of the launch over the SAMPLES is organised (the suffix
+                           launch of the shared-prefix rollout, or the whole rollout); the prefix levels
+                           pick theirs by their class counts.  Costs do not depend on it.  */
   int64_t classes;     /* classes of the last level, summed over chunks      */
   int64_t class_steps; /* sum over levels of classes x steps of the level    */
   int64_t samples;     /* nv * nw                                            */
@@ -254,6 +260,15 @@ int sfw_plan_shared_prefix(const double *linvels, int32_t nv,
                            int32_t n_agents, int32_t *level_ends,
                            int64_t *level_classes, int32_t cap,
                            int32_t *n_levels);
+/* Tuning / test knob: which organisation the social-force kernel's waves use.  SFW_K2_AUTO (default) picks
+ * per launch by agent and item count; SFW_K2_REGISTER / SFW_K2_FLAT force one wherever it exists for the
+ * agent count (register: A <= 128; flat: A >= 2, or laser points).  The organisations are bit-identical in
+ * their results.  Takes effect at the next stage.  SFW_FORCE_FLAT=0|1 in the environment of sfw_create sets
+ * the handle's initial value. */
+#define SFW_K2_AUTO (-1)
+#define SFW_K2_REGISTER 0
+#define SFW_K2_FLAT 1
+int sfw_set_k2_form(sfw_handle h, int32_t form);
 /* Per-kernel HIP events around the kernels of sfw_grid_launch, off by default
  * (a control cycle is latency-bound; four event records cost as much as a
  * kernel).  Measurement tooling (bench.py) switches them on. */

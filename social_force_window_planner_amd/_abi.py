@@ -18,6 +18,9 @@ SFW_COST_SKIPPED = -2.0
 SFW_PRECISION_F64 = 0
 SFW_PRECISION_F32 = 1
 
+SFW_K2_AUTO, SFW_K2_REGISTER, SFW_K2_FLAT = -1, 0, 1
+SFW_ORG_NONE, SFW_ORG_REGISTER_1, SFW_ORG_REGISTER_2, SFW_ORG_FLAT = 0, 1, 2, 3
+
 
 class SfwParams(C.Structure):
     _fields_ = [
@@ -131,12 +134,12 @@ class SfwBestKey(C.Structure):
 
 
 class SfwPlanInfo(C.Structure):
-    _fields_ = [("split_step", C.c_int32), ("levels", C.c_int32), ("chunks", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("split_step", C.c_int32), ("levels", C.c_int32), ("chunks", C.c_int32), ("organisation", C.c_int32),
                 ("classes", C.c_int64), ("class_steps", C.c_int64), ("samples", C.c_int64)]
 
     def as_dict(self):
         return {"split_step": self.split_step, "levels": self.levels, "chunks": self.chunks, "classes": self.classes,
-                "class_steps": self.class_steps, "samples": self.samples}
+                "class_steps": self.class_steps, "samples": self.samples, "organisation": self.organisation}
 
 
 # Every symbol include/sfw_hip.h declares (checked by tests/test_abi.py).
@@ -158,6 +161,7 @@ EXPORTED_SYMBOLS = (
     "sfw_grid_fetch",
     "sfw_grid_plan_info",
     "sfw_plan_shared_prefix",
+    "sfw_set_k2_form",
     "sfw_set_timing",
     "sfw_last_launch_ms",
     "sfw_grid_points",

@@ -135,6 +135,7 @@ struct sfw_planner_s {
   int64_t index_base = 0;
   bool staged = false, launched = false, launched_timed = false;
   bool timing = false;  // sfw_set_timing: record the per-kernel events sfw_last_launch_ms reads
+  int k2_form = SFW_K2_AUTO;     // sfw_set_k2_form / SFW_FORCE_FLAT
 
   // shared-prefix plan of the staged grid (sfw_device.h: sfw_cls_agent); no levels: not used
   struct level_tables {               // offsets (ints) into d_cls
@@ -264,6 +265,7 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.step_begin = 0;
   L.step_end = L.S;
   L.resume = 0;
+  L.k2_form = h->k2_form;
 }
 
 // ---- shared-prefix plan ---------------------------------------------------
@@ -401,7 +403,7 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
     for (int p : h->prefix_env)
       if (p >= 1 && p <= pc.max_p) steps.push_back(p);
   } else {
-    steps = choose_levels(pc, T, S, static_cast<double>(sfw_samples_per_wave(h->st_A, std::min<int64_t>(T, rows_per_chunk * h->nw))));
+    steps = choose_levels(pc, T, S, static_cast<double>(sfw_samples_per_wave(h->st_A, std::min<int64_t>(T, rows_per_chunk * h->nw), h->k2_form)));
   }
   if (steps.empty()) return SFW_OK;
   const size_t n_lv = steps.size();
@@ -548,7 +550,7 @@ int plan_tables(sfw_handle h) {
 
 // The agent / laser-point set must fit one wave's LDS allocation (160 KiB per CU).
 int check_lds(sfw_handle h, int64_t items) {
-  const size_t lds = sfw_social_lds_bytes(h->st_A, h->st_O, h->st_NG, h->st_n_grp_mem, items);
+  const size_t lds = sfw_social_lds_bytes(h->st_A, h->st_O, h->st_NG, h->st_n_grp_mem, items, h->k2_form);
   if (h->st_A > 0 && lds > 160 * 1024)
     return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
   return SFW_OK;
@@ -817,6 +819,7 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
     std::sort(h->prefix_env.begin(), h->prefix_env.end());
     h->prefix_env.erase(std::unique(h->prefix_env.begin(), h->prefix_env.end()), h->prefix_env.end());
   }
+  if (const char *b = std::getenv("SFW_FORCE_FLAT")) h->k2_form = std::atoi(b) == 1 ? SFW_K2_FLAT : std::atoi(b) == 0 ? SFW_K2_REGISTER : SFW_K2_AUTO;
   if (const char *b = std::getenv("SFW_TABLE_BUDGET_MB")) {
     long mb = std::atol(b);
     if (mb > 0) h->table_budget_bytes = static_cast<size_t>(mb) << 20;
@@ -1084,7 +1087,7 @@ int sfw_plan_shared_prefix(const double *linvels, int32_t nv, const double *angv
   if (n_agents < 2 || num_steps < 2 || T < 4096) return SFW_OK;
   const std::vector<double> lin(linvels, linvels + nv), ang(angvels, angvels + nw);
   const prefix_classes pc = classes_of_grid(lin, ang, vx0, vtheta0, acc_x, acc_theta, sim_time / num_steps, num_steps);
-  const std::vector<int> steps = choose_levels(pc, T, num_steps, static_cast<double>(sfw_samples_per_wave(n_agents, T)));
+  const std::vector<int> steps = choose_levels(pc, T, num_steps, static_cast<double>(sfw_samples_per_wave(n_agents, T, SFW_K2_AUTO)));
   *n_levels = static_cast<int32_t>(steps.size());
   for (size_t l = 0; l < steps.size() && l < static_cast<size_t>(cap); ++l) {
     level_ends[l] = steps[l];
@@ -1099,7 +1102,6 @@ int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out) {
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
   out->split_step = h->prefix_steps.empty() ? 0 : h->prefix_steps.back();
   out->levels = static_cast<int32_t>(h->prefix_steps.size());
-  out->reserved = 0;
   out->samples = T;
   out->classes = h->prefix_last_classes;
   out->class_steps = h->prefix_class_steps;
@@ -1111,6 +1113,15 @@ int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out) {
     if (chunk > T) chunk = T;
     out->chunks = chunk > 0 ? static_cast<int32_t>((T + chunk - 1) / chunk) : 0;
   }
+  out->organisation = sfw_social_organisation(h->st_A, out->chunks > 0 ? (T + out->chunks - 1) / out->chunks : T, h->st_O, h->k2_form);
+  return SFW_OK;
+}
+
+int sfw_set_k2_form(sfw_handle h, int32_t form) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  if (form != SFW_K2_AUTO && form != SFW_K2_REGISTER && form != SFW_K2_FLAT)
+    return fail(h, SFW_ERR_INVALID_ARG, "set_k2_form: form must be SFW_K2_AUTO, SFW_K2_REGISTER or SFW_K2_FLAT");
+  h->k2_form = form;
   return SFW_OK;
 }
 

@@ -106,6 +106,7 @@ struct sfw_launch {
   int32_t step_begin, step_end;  // steps this launch integrates
   int32_t resume;                // 1: start from in_state records instead of the initial agents
   int32_t force_alive;           // 1: K2 also integrates samples K1 rejected on the costmap (point dumps only)
+  int32_t k2_form;               // SFW_K2_AUTO / _REGISTER / _FLAT: which organisation of a K2 wave (sfw_set_k2_form)
   int32_t n_cls, n_col_cls;      // PREFIX: classes of this level, its column classes
   const int32_t *row_rep;        // PREFIX [row classes]  chunk-local row whose robot records represent the class
   const int32_t *col_rep;        // PREFIX [n_col_cls]    column likewise
@@ -165,8 +166,10 @@ hipError_t sfw_launch_key_table(const sfw_sel *sel, double *table, int r, int R,
 // Pair table of the flat social kernel for A agents: sfw_pair_table_entries(A) uint16 entries.
 int64_t sfw_pair_table_entries(int A);
 hipError_t sfw_launch_pair_table(uint16_t *tab, int A, hipStream_t stream);
-// Samples handled by one wave of the social kernel for A agents.
-int sfw_samples_per_wave(int A, int64_t T);
-size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T);
+// Samples handled by one wave of the social kernel for A agents (form: SFW_K2_*).
+int sfw_samples_per_wave(int A, int64_t T, int form);
+size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T, int form);
+// SFW_ORG_* of a K2 launch over T items
+int sfw_social_organisation(int A, int64_t T, int O, int form);
 
 #endif  // SFW_DEVICE_H_

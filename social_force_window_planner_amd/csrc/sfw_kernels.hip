@@ -1630,7 +1630,9 @@ __global__ void __launch_bounds__(64) sfw_key_table_kernel(const sfw_sel *sel, d
 // All organisations produce bit-identical costs (tools/kernel_equiv.py), so the choice
 // never shows in the results.
 struct wave_plan { int G; int ns; bool flat; };
-static wave_plan plan_for(int A, int64_t T, int O = 0) {
+// form: SFW_K2_AUTO, or SFW_K2_REGISTER / SFW_K2_FLAT forced by the caller (sfw_set_k2_form, SFW_FORCE_FLAT in the
+// environment of sfw_create) — honoured wherever the form exists for A (register: 1 <= A <= 128; flat: A >= 2 or O > 0).
+static wave_plan plan_for(int A, int64_t T, int O, int form) {
   wave_plan best{1, 0, true};
   if (A <= 0) return wave_plan{1, 1, false};
   const int P = A * (A - 1) / 2;
@@ -1645,15 +1647,19 @@ static wave_plan plan_for(int A, int64_t T, int O = 0) {
   }
   // ... and a robot alone among laser points: the flat form spreads the points over eight lanes
   if (T <= 4096 && (A >= 2 || O > 0)) best = wave_plan{1, 0, true};
-  static const char *const e = getenv("SFW_FORCE_FLAT");  // tuning override, read once
-  if (e) {
-    if (atoi(e) == 1 && (A >= 2 || O > 0)) best = wave_plan{1, 0, true};
-    if (atoi(e) == 0 && A <= 2 * WAVE) best = (A <= WAVE) ? wave_plan{WAVE / A, 1, false} : wave_plan{1, 2, false};
-  }
+  if (form == SFW_K2_FLAT && (A >= 2 || O > 0)) best = wave_plan{1, 0, true};
+  if (form == SFW_K2_REGISTER && A <= 2 * WAVE) best = (A <= WAVE) ? wave_plan{WAVE / A, 1, false} : wave_plan{1, 2, false};
   return best;
 }
 
-int sfw_samples_per_wave(int A, int64_t T) { return plan_for(A, T).G; }
+int sfw_samples_per_wave(int A, int64_t T, int form) { return plan_for(A, T, 0, form).G; }
+
+// SFW_ORG_* of the launch plan_for() picks for T items
+int sfw_social_organisation(int A, int64_t T, int O, int form) {
+  if (A <= 0) return SFW_ORG_NONE;
+  const wave_plan pl = plan_for(A, T, O, form);
+  return pl.flat ? SFW_ORG_FLAT : pl.ns == 2 ? SFW_ORG_REGISTER_2 : SFW_ORG_REGISTER_1;
+}
 
 void sfw_derive(sfw_launch &L) {
   const sfw_params &p = L.p;
@@ -1695,8 +1701,8 @@ static size_t lds_bytes_for(const wave_plan &pl, int A, int O, int NG, int n_grp
 
 // Largest LDS allocation any launch of a chunk of T samples may ask for (the prefix phase of the
 // shared-prefix rollout may pick the flat organisation where the chunk itself uses the other).
-size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T) {
-  const size_t a = lds_bytes_for(plan_for(A, T, O), A, O, NG, n_grp_mem);
+size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T, int form) {
+  const size_t a = lds_bytes_for(plan_for(A, T, O, form), A, O, NG, n_grp_mem);
   const size_t b = (A >= 2 || O > 0) ? lds_bytes_for(wave_plan{1, 0, true}, A, O, NG, n_grp_mem) : 0;
   return a > b ? a : b;
 }
@@ -1767,7 +1773,7 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L,
   // organisation-neutral, so every launch picks its own by its item count (measured: forcing the
   // flat form on an under-filled prefix phase at cfg2 — 2024 register-form waves — changes nothing).
   const int64_t items = L.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L.n_cls) : L.chunk_count;
-  const wave_plan pl = plan_for(L.A, items, L.O);
+  const wave_plan pl = plan_for(L.A, items, L.O, L.k2_form);
   const unsigned grid = static_cast<unsigned>((items + pl.G - 1) / pl.G);
   const size_t lds = lds_bytes_for(pl, L.A, L.O, L.NG, L.n_grp_mem);
   if (lds > 160 * 1024) return hipErrorInvalidValue;

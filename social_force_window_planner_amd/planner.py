@@ -84,6 +84,7 @@ def lib():
         L.sfw_grid_sync.argtypes = [vp]
         L.sfw_grid_fetch.argtypes = [vp, vp, C.POINTER(SfwBest), C.POINTER(SfwBestKey)]
         L.sfw_grid_plan_info.argtypes = [vp, C.POINTER(SfwPlanInfo)]
+        L.sfw_set_k2_form.argtypes = [vp, C.c_int32]
         L.sfw_set_timing.argtypes = [vp, C.c_int32]
         L.sfw_last_launch_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
         L.sfw_grid_points.argtypes = [vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32)]
@@ -225,6 +226,11 @@ class HipScorer:
         info = SfwPlanInfo()
         self._check(lib().sfw_grid_plan_info(self._h, C.byref(info)), "sfw_grid_plan_info")
         return info.as_dict()
+
+    def set_k2_form(self, form):
+        """SFW_K2_AUTO / SFW_K2_REGISTER / SFW_K2_FLAT: the organisation of the social-force kernel's waves
+        (bit-identical results; tests and tuning)."""
+        self._check(lib().sfw_set_k2_form(self._h, form), "sfw_set_k2_form")
 
     def set_timing(self, enabled=True):
         """Per-kernel HIP events for last_launch_ms (off by default: latency path)."""

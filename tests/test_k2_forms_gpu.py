@@ -1,0 +1,179 @@
+"""Every instantiation of the social-force kernel K2 against the oracle ("next round" 1).
+
+K2 has two organisations of a wave — register-resident agent slots (`sfw_social_kernel<R, NS, GROUPS>`, NS = 1 for
+A <= 64 with floor(64/A) samples per wave, NS = 2 for 64 < A <= 128) and all pairs flattened over the lanes
+(`sfw_social_kernel_flat<R, GROUPS, CAP>`) — and the launcher picks one per launch by agent and item count: a grid
+of at most 4096 samples always runs flat.  The small grids the oracle can follow therefore never reached the
+register-resident family unless it was forced.  Here every scene is scored under sfw_set_k2_form(SFW_K2_REGISTER) AND
+sfw_set_k2_form(SFW_K2_FLAT), the organisation that really ran is read back from sfw_grid_plan_info, and both are
+held to the oracle (f64: 1e-9, f32 forces: the north-star 1e-4) — not merely to each other.
+
+Reference being matched: sfm::SFM.computeForces / updatePosition (group, obstacle and pair forces) reached from
+/root/reference/src/sfw_planner.cpp:592-594, computeSocialWork :678-705, group ids src/sensor_interface.cpp:448-449.
+"""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from social_force_window_planner_amd import synthetic as syn
+from social_force_window_planner_amd._abi import (SFW_K2_AUTO, SFW_K2_FLAT, SFW_K2_REGISTER, SFW_ORG_FLAT,
+                                                   SFW_ORG_REGISTER_1, SFW_ORG_REGISTER_2, SFW_PRECISION_F32,
+                                                   SFW_PRECISION_F64, default_params)
+
+from test_parity_gpu import RTOL_F64, RTOL_NORTH_STAR, _assert_parity, _grouped_scene
+from test_parity_holes_gpu import _rest_scene
+
+pytestmark = pytest.mark.gpu
+
+FORMS = [pytest.param(SFW_K2_REGISTER, id="register"), pytest.param(SFW_K2_FLAT, id="flat")]
+PRECISIONS = [pytest.param(SFW_PRECISION_F64, RTOL_F64, id="f64"), pytest.param(SFW_PRECISION_F32, RTOL_NORTH_STAR, id="f32")]
+
+
+def _expected_org(form, A):
+    if form == SFW_K2_FLAT:
+        return SFW_ORG_FLAT
+    return SFW_ORG_REGISTER_1 if A <= 64 else SFW_ORG_REGISTER_2
+
+
+def _check(oracle_mod, hip_mod, scene, form, prec, rtol, rs=None, n_threads=16):
+    rs = scene.robot_state if rs is None else rs
+    w = scene.workload
+    kw = dict(sim_time=w.sim_time, sim_granularity=w.sim_granularity)
+    o = oracle_mod.OracleScorer(default_params(**kw))  # the oracle is always f64
+    o.load_scene(scene)
+    g = hip_mod.HipScorer(default_params(precision=prec, **kw))
+    g.set_k2_form(form)
+    g.load_scene(scene)
+    g.stage(rs, scene.linvels, scene.angvels, scene.goal_args)
+    org = g.plan_info()["organisation"]
+    assert org == _expected_org(form, len(scene.agents)), f"organisation {org} ran, not the requested one"
+    g.launch()
+    gc, gb, _ = g.fetch()
+    oc, ob = o.score_grid(rs, scene.linvels, scene.angvels, scene.goal_args, n_threads=n_threads)
+    assert (oc >= 0).sum() >= 4, "scene has too few valid samples to say anything"
+    if prec == SFW_PRECISION_F64:
+        _assert_parity(oc, ob, gc, gb, rtol)
+    else:
+        assert np.array_equal(oc < 0, gc < 0)
+        v = oc >= 0
+        rel = np.abs(gc[v] - oc[v]) / np.abs(oc[v])
+        assert rel.max() <= rtol, f"max rel err {rel.max():.3e}"
+        if gb["index"] != ob["index"]:  # only legal when the oracle itself cannot separate the two
+            assert abs(oc[gb["index"]] - ob["cost"]) <= rtol * ob["cost"]
+    return gc
+
+
+# (a) group forces in the GROUPS = true instantiations: A = 21 (three samples per wave in the register form),
+#     A = 60 (one sample per wave), A = 100 (two slots per lane)
+@pytest.mark.parametrize("prec,rtol", PRECISIONS)
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("n_people", [20, 59, 99])
+def test_groups(oracle_mod, hip_mod, n_people, form, prec, rtol):
+    scene = _grouped_scene(n_people, 10 + n_people)
+    _check(oracle_mod, hip_mod, scene, form, prec, rtol)
+
+
+# (b) slot-count boundaries without groups: G = 1 with one slot per lane (A = 52, 64), two slots per lane (A = 65,
+#     111, 128), several samples per wave (A = 2, 7, 21, 32)
+@pytest.mark.parametrize("prec,rtol", PRECISIONS)
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("n_people", [1, 6, 20, 31, 51, 63, 64, 110, 127])
+def test_agent_counts(oracle_mod, hip_mod, n_people, form, prec, rtol):
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=6, nw=7, n_people=n_people, seed=700 + n_people)
+    _check(oracle_mod, hip_mod, syn.make_scene(w), form, prec, rtol)
+
+
+# (c) pairs at exact relative rest (the host-evaluated angular terms, L.agent_rest, are added in both organisations)
+@pytest.mark.parametrize("prec,rtol", PRECISIONS)
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("n_people,robot_moving", [(20, True), (20, False), (70, True)])
+def test_relative_rest(oracle_mod, hip_mod, n_people, robot_moving, form, prec, rtol):
+    scene, rs = _rest_scene(n_people, 520 + n_people, robot_moving, nv=6, nw=7)
+    _check(oracle_mod, hip_mod, scene, form, prec, rtol, rs=rs)
+
+
+# (d) laser points: O = 64 at A = 21 (BASELINE-adjacent `cfg2_o64`), O = 7 with groups, O = 1, O = 240 with two slots
+@pytest.mark.parametrize("prec,rtol", PRECISIONS)
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("n_people,n_obs,grouped,seed", [(20, 64, False, 0), (20, 7, True, 60), (59, 7, True, 99), (20, 1, False, 0),
+                                                         (99, 240, False, 0), (99, 33, True, 43), (99, 33, True, 56), (0, 16, False, 0)])
+def test_laser_points(oracle_mod, hip_mod, n_people, n_obs, grouped, seed, form, prec, rtol):
+    if grouped:  # seeds 43 / 56: a third of the samples end in a pedestrian contact
+        scene = _grouped_scene(n_people, seed, n_obstacles=n_obs)
+    else:
+        w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=6, nw=7, n_people=n_people, seed=800 + n_people + n_obs,
+                                n_obstacles=n_obs)
+        scene = syn.make_scene(w)
+    if n_people == 0 and form == SFW_K2_FLAT:
+        pytest.skip("A = 1 has no flat/register distinction worth two runs")
+    _check(oracle_mod, hip_mod, scene, form, prec, rtol)
+
+
+# (e) a GPU-filling grid (> 4096 samples): the organisation the automatic plan picks, through the shared-prefix tree
+@pytest.mark.parametrize("kind", ["groups", "rest", "o64", "plain52"])
+def test_gpu_filling_grid_automatic_plan(oracle_mod, hip_mod, kind):
+    nv, nw = (72, 64) if kind == "plain52" else (96, 96)  # enough register-form waves (three samples each) for sharing to pay
+    rs = None
+    if kind == "groups":
+        scene = _grouped_scene(20, 71, nv=nv, nw=nw)
+    elif kind == "rest":
+        scene, rs = _rest_scene(20, 504, True, nv=nv, nw=nw)
+    elif kind == "o64":
+        scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["cfg2_o64"], nv=nv, nw=nw))
+    else:
+        scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["cfg2"], nv=nv, nw=nw, n_people=51, seed=752))
+    rs = scene.robot_state if rs is None else rs
+    p = default_params()
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    g.stage(rs, scene.linvels, scene.angvels, scene.goal_args)
+    info = g.plan_info()
+    assert info["levels"] > 0, "no shared-prefix tree on a GPU-filling grid"
+    # 21 agents: three samples per register-form wave; 52 agents: the flat form wins (81 % of the lanes otherwise)
+    assert info["organisation"] == (SFW_ORG_FLAT if kind == "plain52" else SFW_ORG_REGISTER_1)
+    g.launch()
+    gc, gb, _ = g.fetch()
+    o = oracle_mod.OracleScorer(p)
+    o.load_scene(scene)
+    rows = [0, 35, nv - 1]
+    oc, _ = o.score_grid(rs, scene.linvels[rows], scene.angvels, scene.goal_args, n_threads=64)
+    sub = gc.reshape(nv, nw)[rows].ravel()
+    assert np.array_equal(oc < 0, sub < 0)
+    v = oc >= 0
+    assert v.sum() > 20
+    assert np.max(np.abs(sub[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64
+    # ... and the other organisation, forced, gives bit-identical costs on the whole grid
+    g2 = hip_mod.HipScorer(p)
+    g2.set_k2_form(SFW_K2_REGISTER if info["organisation"] == SFW_ORG_FLAT else SFW_K2_FLAT)
+    g2.load_scene(scene)
+    c2, b2 = g2.score_grid(rs, scene.linvels, scene.angvels, scene.goal_args)
+    assert g2.plan_info()["organisation"] != info["organisation"]
+    assert np.array_equal(gc, c2) and b2 == gb
+
+
+def test_forms_are_bit_identical_and_the_knob_validates(hip_mod):
+    """The two organisations sum every accumulator in the same order: equal bits, not just equal to 1e-9."""
+    from social_force_window_planner_amd.planner import SfwError
+
+    for n_people, n_obs in [(5, 0), (20, 0), (20, 9), (63, 0), (100, 0), (127, 3)]:
+        w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=5, nw=7, n_people=n_people, seed=400 + n_people, n_obstacles=n_obs)
+        scene = syn.make_scene(w)
+        res = []
+        for form in (SFW_K2_AUTO, SFW_K2_REGISTER, SFW_K2_FLAT):
+            g = hip_mod.HipScorer(default_params())
+            g.set_k2_form(form)
+            g.load_scene(scene)
+            res.append(g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args))
+        for c, b in res[1:]:
+            assert np.array_equal(c, res[0][0]) and b == res[0][1]
+    g = hip_mod.HipScorer(default_params())
+    with pytest.raises(SfwError):
+        g.set_k2_form(7)
+    # more than 128 agents: the register form does not exist, the request falls back to the flat form
+    w = dataclasses.replace(syn.WORKLOADS["cfg4"], nv=2, nw=3, sim_time=0.1)
+    scene = syn.make_scene(w)
+    g.set_k2_form(SFW_K2_REGISTER)
+    g.load_scene(scene)
+    g.stage(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert g.plan_info()["organisation"] == SFW_ORG_FLAT

@@ -377,13 +377,13 @@ def test_f32_forces_mode_within_north_star_tolerance(oracle_mod, hip_mod, name, 
 # ---------------------------------------------------------------------------
 # group forces: grouped pedestrians, several group shapes
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("n_people,seed", [(6, 1), (20, 2), (50, 3), (70, 4)])
-def test_group_forces(oracle_mod, hip_mod, n_people, seed):
-    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=6, nw=7, n_people=n_people, seed=300 + seed)
+def _grouped_scene(n_people, seed, nv=6, nw=7, n_obstacles=0):
+    """Groups of 2-4 neighbours walking the same way (close enough for the repulsion term), one singleton
+    group, the rest ungrouped."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=nv, nw=nw, n_people=n_people, seed=300 + seed, n_obstacles=n_obstacles)
     scene = syn.make_scene(w)
     rng = np.random.default_rng(seed)
     ag = scene.agents
-    # groups of 2-4 neighbours walking the same way, one singleton group, the rest ungrouped
     order = np.argsort([math.atan2(ag[i].y, ag[i].x) for i in range(1, n_people + 1)]) + 1
     gid, k = 0, 0
     while k + 1 < min(n_people, 14):
@@ -394,14 +394,20 @@ def test_group_forces(oracle_mod, hip_mod, n_people, seed):
             a = ag[int(m)]
             a.group_id = gid
             a.x, a.y = lead.x + rng.uniform(-0.5, 0.5), lead.y + rng.uniform(-0.5, 0.5)   # close: repulsion fires
-            # same heading, slightly different speeds: exact relative rest (w = 0) is the one
-            # configuration where the reference's theta is rounding noise (DESIGN.md "deviations")
+            # same heading, slightly different speeds (exact relative rest has its own tests, test_parity_holes_gpu.py)
             sc = 1.0 + 0.02 * float(rng.uniform(-1, 1))
             a.vx, a.vy = lead.vx * sc + 0.01 * float(rng.uniform(-1, 1)), lead.vy * sc
             a.goal_x, a.goal_y = a.x + 2.0 * a.vx, a.y + 2.0 * a.vy
         gid, k = gid + 1, k + size
     if n_people > 16:
         ag[int(order[15])].group_id = 99   # group of one: no group force
+    return scene
+
+
+@pytest.mark.parametrize("n_people,seed", [(6, 1), (20, 2), (50, 3), (70, 4)])
+def test_group_forces(oracle_mod, hip_mod, n_people, seed):
+    scene = _grouped_scene(n_people, seed)
+    ag = scene.agents
     oc0 = None
     for prec, rtol in ((0, RTOL_F64), (SFW_PRECISION_F32, RTOL_NORTH_STAR)):
         p = default_params(precision=prec)

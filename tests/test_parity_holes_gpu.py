@@ -102,18 +102,22 @@ def test_pairs_at_exact_relative_rest(oracle_mod, hip_mod, n_people, seed, robot
 
 
 def test_relative_rest_on_a_gpu_filling_grid(oracle_mod, hip_mod):
-    """The same through the shared-prefix tree and the register-resident organisation (64 x 64 samples)."""
-    scene, rs = _rest_scene(20, 504, True, nv=64, nw=64)
+    """The same through the shared-prefix tree and the register-resident organisation: 96 x 96 samples (a grid of
+    at most 4096 samples runs the flat form), checked through sfw_grid_plan_info."""
+    from social_force_window_planner_amd._abi import SFW_ORG_REGISTER_1
+
+    scene, rs = _rest_scene(20, 504, True, nv=96, nw=96)
     p = default_params()
     g = hip_mod.HipScorer(p)
     g.load_scene(scene)
     gc, gb = g.score_grid(rs, scene.linvels, scene.angvels, scene.goal_args)
-    assert g.plan_info()["levels"] > 0
+    info = g.plan_info()
+    assert info["levels"] > 0 and info["organisation"] == SFW_ORG_REGISTER_1
     o = oracle_mod.OracleScorer(p)
     o.load_scene(scene)
-    rows = [0, 21, 63]
+    rows = [0, 21, 95]
     oc, _ = o.score_grid(rs, scene.linvels[rows], scene.angvels, scene.goal_args, n_threads=8)
-    sub = gc.reshape(64, 64)[rows].ravel()
+    sub = gc.reshape(96, 96)[rows].ravel()
     assert np.array_equal(oc < 0, sub < 0)
     v = oc >= 0
     assert np.max(np.abs(sub[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64
