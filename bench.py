@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads under `extra`")
-    ap.add_argument("--extras", default="cfg5_strong,upload,resident,cfg2,cfg2_o64,cfg3,cfg4,f32",
+    ap.add_argument("--extras", default="cfg5_strong,inproc_multi,upload,resident,cfg2,cfg2_o64,cfg3,cfg4,f32",
                     help="comma-separated secondary measurements to run (all by default)")
     ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each secondary workload")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -220,13 +220,17 @@ def run_config(workload_name, precision, steps, warmup, ctx, scaling="weak", res
         tot = torch.tensor([float(job.n_scored)], dtype=torch.float64, device=cd)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         n_scored_total = int(tot.item())
-        mine = torch.zeros((world, 3), dtype=torch.float64, device=cd)
+        mine = torch.zeros((world, 5), dtype=torch.float64, device=cd)
         mine[rank] = torch.tensor([float(np.mean(k2_ms)), float(np.median(wall)) * 1e3,
-                                   float(np.median(state["xchg"])) * 1e6], dtype=torch.float64)
+                                   float(np.median(state["xchg"])) * 1e6, executed_share_of(job),
+                                   job.scorer.sustained_clock_ghz()], dtype=torch.float64)
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)
         tab = mine.cpu().numpy()
+        # executed_share differs per rank: every block of rows spans another velocity range, so its shared-prefix tree
+        # saves another share of the steps — K2 time per rank follows it (read the imbalance here, not as "efficiency")
         per_rank = {"social_kernel_ms": tab[:, 0].tolist(), "median_step_ms": tab[:, 1].tolist(),
-                    "exchange_us": tab[:, 2].tolist()}
+                    "exchange_us": tab[:, 2].tolist(), "executed_share": tab[:, 3].tolist(),
+                    "sustained_clock_ghz": tab[:, 4].tolist()}
         win_rank, win_key = state["win"]
     else:
         n_scored_total = job.n_scored
@@ -248,6 +252,45 @@ def run_config(workload_name, precision, steps, warmup, ctx, scaling="weak", res
     }
 
 
+def inproc_multi(workload_name, precision, devices, exchange, steps, warmup):
+    """sfw_multi_score_grid itself — ONE process driving len(devices) ranks, the shape the reference's plugin has
+    (one process, sfw_plugin.xml:1-9; rows are the outer axis, src/sfw_planner.cpp:345): blocking call incl. the cost
+    vector, host wall-clock per phase from sfw_multi_last_us."""
+    from social_force_window_planner_amd import synthetic as syn
+    from social_force_window_planner_amd._abi import SFW_PRECISION_F32, SFW_PRECISION_F64, default_params
+    from social_force_window_planner_amd.planner import MultiScorer, plan_info_of_rank
+
+    w = syn.WORKLOADS[workload_name]
+    scene = syn.make_scene(dataclasses.replace(w, nv=2, nw=2))
+    lin, ang = syn.generalised_sampler(w.nv, w.nw)
+    prec = SFW_PRECISION_F32 if precision == "f32" else SFW_PRECISION_F64
+    m = MultiScorer(default_params(precision=prec, sim_time=w.sim_time, sim_granularity=w.sim_granularity),
+                    devices=tuple(devices), exchange=exchange)
+    try:
+        m.load_scene(scene)
+        for _ in range(warmup):
+            m.score_grid(scene.robot_state, lin, ang, scene.goal_args)
+        wall, us = [], []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            _, best = m.score_grid(scene.robot_state, lin, ang, scene.goal_args)
+            wall.append(time.perf_counter() - t0)
+            us.append(m.last_us())
+        zero = int(np.any(lin == 0.0) and np.any(ang == 0.0))
+        med = float(np.median(wall))
+        return {
+            "ranks": len(devices), "devices": list(devices), "exchange": "rccl" if exchange == 0 else "host_reduce",
+            "steps": steps, "ms_per_call": med * 1e3, "value": (w.nv * w.nw - zero) / med, "unit": "trajectories/s",
+            "enqueue_us": float(np.median([u["enqueue_us"] for u in us])),
+            "exchange_us": float(np.median([u["exchange_us"] for u in us])),
+            "fetch_us": float(np.median([u["fetch_us"] for u in us])),
+            "levels_rank0": plan_info_of_rank(m, 0)["levels"],
+            "cmd_vel_index": best["index"],
+        }
+    finally:
+        m.close()
+
+
 def measured_traffic(workload_name):
     """HBM bytes per launch from the committed PMC passes (profiles/r0N_traffic.json, newest first), or None."""
     for name in ("r02_traffic.json", "r01_traffic.json"):
@@ -261,6 +304,15 @@ def measured_traffic(workload_name):
         except (OSError, ValueError):
             pass
     return None
+
+
+def executed_share_of(job):
+    """Share of the algorithmic sample-steps this rank really integrates (shared-prefix tree + suffix)."""
+    plan, S = job.plan, job.workload.n_steps
+    total = plan["samples"] * S
+    if plan["levels"] <= 0 or not total:
+        return 1.0
+    return (plan["class_steps"] + plan["samples"] * (S - plan["split_step"])) / total
 
 
 def roofline_for(job, k2_ms, precision, brief=False):
@@ -387,7 +439,7 @@ def main():
         "median_ms_per_step": res["median_step_ms"],
         "value_at_median": job.n_scored * world / (res["median_step_ms"] * 1e-3) if world == 1 else None,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if world > 1 else None,
         "vs_baseline": None,
         "dtype": args.precision,
         "data": "synthetic (seeded costmap/people per SURVEY.md §8d)",
@@ -419,20 +471,35 @@ def main():
     wanted = set() if (args.no_extra or args.resident) else set(args.extras.split(","))
     if "cfg5_strong" in wanted:
         # BASELINE.json config 5 sharded over the N ranks (strong scaling); N = 1: the whole
-        # 16.8 M-sample grid on one GPU, in table chunks
+        # 16.8 M-sample grid on one GPU, in table chunks.  One probe step sizes the run: >= 5 timed steps when a step
+        # takes < 3 s, 3 otherwise.
         del job, res
-        r5 = run_config("cfg5", args.precision, 2, 1, ctx, scaling="strong")
+        probe = run_config("cfg5", args.precision, 1, 1, ctx, scaling="strong")
+        n5 = 5 if probe["elapsed"] < 3.0 else 3
+        del probe
+        r5 = run_config("cfg5", args.precision, n5, 0, ctx, scaling="strong")
         j5 = r5["job"]
         extra["cfg5_strong"] = {
             "workload": workload_text(j5.workload) + f", rows sharded over {world} GPU(s)",
-            "value": r5["n_scored_total"] * 2 / r5["elapsed"], "unit": "trajectories/s", "steps": 2, "warmup": 1,
-            "ms_per_step": r5["elapsed"] / 2 * 1e3, "n_gpus": world, "scaling": "strong",
+            "value": r5["n_scored_total"] * n5 / r5["elapsed"], "unit": "trajectories/s", "steps": n5, "warmup": 2,
+            "ms_per_step": r5["elapsed"] / n5 * 1e3, "n_gpus": world, "scaling": "strong",
             "samples_per_gpu": j5.n_local, "chunks_per_gpu": j5.plan["chunks"],
             "per_rank": r5["per_rank"] or {"social_kernel_ms": [r5["k2_ms"]], "median_step_ms": [r5["median_step_ms"]],
-                                           "exchange_us": [0.0]},
+                                           "exchange_us": [0.0], "executed_share": [executed_share_of(j5)]},
             "roofline_frac_rank0": roofline_for(j5, r5["k2_ms"], args.precision, brief=True),
         }
         del j5, r5
+    if "inproc_multi" in wanted and world > 1:
+        # The plugin-shaped path at N > 1: rank 0 ALONE drives all N devices from one process through
+        # sfw_multi_score_grid over SFW_MULTI_RCCL (ncclCommInitAll + one grouped ncclAllReduce(min) per call); the other
+        # ranks wait at the barrier below.  Same cfg5 grid as extra.cfg5_strong, so the two paths' numbers sit side by side.
+        if rank == 0:
+            try:
+                extra["inproc_multi_cfg5"] = inproc_multi("cfg5", args.precision, list(range(world)), 0, 3, 1)
+                extra["inproc_multi_target"] = inproc_multi(args.workload, args.precision, list(range(world)), 0, 20, 3)
+            except Exception as e:  # a broken RCCL install must not take the headline line down
+                extra["inproc_multi_cfg5"] = {"error": repr(e)}
+        dist.barrier()
     if rank == 0 and world == 1 and not args.resident:
         job = GridJob(args.workload, args.precision, 0, 1, local_rank)
         if args.verify:
@@ -449,6 +516,19 @@ def main():
             v = oc >= 0
             out["verify"] = {"max_rel_err": float((np.abs(gc[v] - oc[v]) / np.abs(oc[v])).max()),
                              "same_invalid_set": bool(np.array_equal(oc < 0, gc < 0)), "rows": len(rows)}
+        if "inproc_multi" in wanted:
+            # sfw_multi_score_grid on the one visible device: R host-reduce ranks sharing it (row blocks, worker thread per
+            # rank, column plan shared).  What scales here is the HOST side: the enqueue phase must not grow with R.
+            from social_force_window_planner_amd._abi import SFW_MULTI_HOST_REDUCE
+
+            im = {}
+            for R in (1, 2, 4, 8):
+                im[f"R{R}"] = inproc_multi(args.workload, args.precision, [local_rank] * R, SFW_MULTI_HOST_REDUCE,
+                                           max(5, args.steps // 2), 2)
+            im["enqueue_us_R8_over_R1"] = im["R8"]["enqueue_us"] / im["R1"]["enqueue_us"]
+            im["note"] = ("one process, R handles on ONE device (the box has one GPU): kernels of the ranks share the GPU, so "
+                          "ms_per_call is not a scaling curve; enqueue_us is the host cost of staging + launching all ranks")
+            extra["inproc_multi"] = im
         if "upload" in wanted:
             t0 = time.perf_counter()
             reps = 5

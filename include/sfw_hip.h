@@ -23,7 +23,9 @@
  *
  * Error convention: every function returns SFW_OK (0) or a negative
  * sfw_status.  An invalid trajectory is DATA, not an error: its cost is
- * exactly -1.0 (src/sfw_planner.cpp:549,561,572,625), never NaN.
+ * exactly -1.0 (src/sfw_planner.cpp:549,561,572,625), never NaN.  Non-finite
+ * inputs (agents, laser points, robot state, goal arguments, sample
+ * velocities) are refused with SFW_ERR_INVALID_ARG, so no NaN reaches a cost.
  */
 #ifndef SFW_HIP_H_
 #define SFW_HIP_H_
@@ -108,7 +110,13 @@ typedef struct sfw_agent {
                               twist, as in sensor_interface.cpp:566-575     */
   double goal_x, goal_y;   /* goals.front().center (ignored if !has_goal)   */
   double goal_radius;      /* goals.front().radius                          */
-  double desired_velocity; /* Agent::desiredVelocity                        */
+  double desired_velocity; /* Agent::desiredVelocity; must be > 0 for a person
+                              (index >= 1): one that can never move would be
+                              at exact relative rest with its like at every
+                              step, where the reference's interaction angle
+                              is libm rounding noise (only the handed-over
+                              state's such pairs are reproduced, DESIGN.md
+                              §5) -> SFW_ERR_UNSUPPORTED                    */
   double radius;           /* Agent::radius                                 */
   int32_t has_goal;        /* goals non-empty (people: 1, robot at t0: 0)   */
   int32_t id;              /* Agent::id — the robot-on-person force skips a
@@ -179,7 +187,9 @@ int sfw_set_costmap(sfw_handle h, const uint8_t *cells, uint32_t size_x,
  * (src/costmap_model.cpp:41-48). */
 int sfw_set_footprint(sfw_handle h, const double *xy, int32_t K);
 /* agents[0] = robot.  obstacles_xy: O laser points shared by every agent's
- * obstacles1 (src/sensor_interface.cpp:513-524). */
+ * obstacles1 (src/sensor_interface.cpp:513-524).  At most 8190 agents
+ * (SFW_ERR_UNSUPPORTED beyond; a set that does not fit one wave's 160 KiB of
+ * LDS — roughly 2000 agents — is refused by the scoring call the same way). */
 int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A,
                    const double *obstacles_xy, int32_t O);
 
@@ -277,6 +287,11 @@ int sfw_set_timing(sfw_handle h, int32_t enabled);
  * timing was on): which = 0 whole launch, 1 rollout kernels, 2 social-force
  * kernel, 3 argmin. */
 int sfw_last_launch_ms(sfw_handle h, int32_t which, float *ms_out);
+/* Shader clock (GHz) the social-force kernel of the most recent timed sfw_grid_launch really ran at: wave 0 of the
+ * launch over the samples reads the core-clock and the constant-rate counters when it starts and when it ends.
+ * 0.0 when there was nothing to sample (no agents).  Boxes and thermal states differ by ~10 %: a kernel time is
+ * only comparable across runs next to this number.  SFW_ERR_STATE unless timing was on. */
+int sfw_last_clock_ghz(sfw_handle h, double *ghz_out);
 /* Optional dump of the per-step robot poses of sample `index` of the last
  * launch (Trajectory points for RViz markers, :366-374). */
 int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth,

@@ -164,6 +164,7 @@ EXPORTED_SYMBOLS = (
     "sfw_set_k2_form",
     "sfw_set_timing",
     "sfw_last_launch_ms",
+    "sfw_last_clock_ghz",
     "sfw_grid_points",
     "sfw_grid_points_batch",
     "sfw_stream",

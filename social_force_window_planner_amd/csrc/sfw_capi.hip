@@ -6,11 +6,14 @@
 #include "sfw_device.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -156,6 +159,8 @@ struct sfw_planner_s {
   dev_buf<int32_t> d_cls, cls_dead[2];
   dev_buf<sfw_cls_agent> cls_state[2];  // ping-pong between levels
   std::vector<int> prefix_env;          // SFW_PREFIX: empty automatic, {0} off, else forced split steps
+  const void *shared_cols = nullptr;    // axis_classes of the angular targets lent by sfw_multi_score_grid for the stage in
+                                        // progress (every rank has the same column axis), else null
 
   // per-sample outputs + per-chunk table
   dev_buf<int32_t> status, coll_step;
@@ -167,6 +172,7 @@ struct sfw_planner_s {
   sfw_sel *d_sel = nullptr;
   dev_buf<double> points;
   dev_buf<int32_t> n_points;
+  dev_buf<unsigned long long> clock;  // sfw_launch.clock_probe (timing only)
   dev_buf<char> one_out;  // sfw_score_one: cost | n_points | coll_step | points, contiguous -> one D2H
   // scratch outputs of sfw_grid_points_batch's K1 re-run (kept across calls: hipMalloc/hipFree synchronise the device)
   dev_buf<int32_t> pts_status, pts_coll;
@@ -194,6 +200,12 @@ int hip_fail(sfw_handle h, hipError_t e, const char *what) {
     hipError_t e_ = (call);                                \
     if (e_ != hipSuccess) return hip_fail((h), e_, #call); \
   } while (0)
+
+bool all_finite(const double *v, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (!std::isfinite(v[i])) return false;
+  return true;
+}
 
 int num_steps_of(const sfw_params &p) {
   int n = static_cast<int>(p.sim_time / p.sim_granularity + 0.5);  // ref :519
@@ -327,25 +339,53 @@ double step_cost(double items, double items_per_wave) {
   return x <= 1.0 ? 0.45 + 0.55 * x : x;
 }
 
-// Everything plan_prefix derives from the staged sample vectors alone (no device involved).
-struct prefix_classes {
-  std::vector<std::vector<int32_t>> rc, cc;  // row / column classes per number of compared steps
-  std::vector<int32_t> nr, nc;               // class counts
+// Classes of ONE axis of the grid (velocity_classes of the linear or of the angular targets).
+struct axis_classes {
+  std::vector<std::vector<int32_t>> c;  // per number of compared steps: class of every value
+  std::vector<int32_t> n;               // class counts
+  // what they were derived from (a shared copy is only reused for exactly these inputs)
+  std::vector<double> targets;
+  double v0 = 0, a_max = 0, dt = 0;
   int max_p = 0;
+  bool made_for(const std::vector<double> &t, double v0_, double a_, double dt_, int mp) const {
+    return v0 == v0_ && a_max == a_ && dt == dt_ && max_p == mp && targets == t;
+  }
+};
+axis_classes classes_of_axis(const std::vector<double> &targets, double v0, double a_max, double dt, int max_p) {
+  axis_classes a;
+  a.targets = targets;
+  a.v0 = v0;
+  a.a_max = a_max;
+  a.dt = dt;
+  a.max_p = max_p;
+  velocity_classes(targets, v0, a_max, dt, max_p, a.c, a.n);
+  return a;
+}
+int prefix_max_p(int S) { return std::min(S - 1, 48); }
+
+// Everything plan_prefix derives from the staged sample vectors alone (no device involved).  The column axis may be
+// borrowed (`shared_cols`): every rank of a multi-device grid has the same angular targets.
+struct prefix_classes {
+  axis_classes rows, own_cols;
+  const axis_classes *cols = nullptr;
+  int max_p = 0;
+  const std::vector<std::vector<int32_t>> &rc() const { return rows.c; }
+  const std::vector<std::vector<int32_t>> &cc() const { return cols->c; }
   // a level past the last computed one has every value in its own class
-  const std::vector<int32_t> &rows_at(int p) const { return rc[std::min<size_t>(static_cast<size_t>(p), rc.size()) - 1]; }
-  const std::vector<int32_t> &cols_at(int p) const { return cc[std::min<size_t>(static_cast<size_t>(p), cc.size()) - 1]; }
-  int32_t n_rows_at(int p) const { return nr[std::min<size_t>(static_cast<size_t>(p), nr.size()) - 1]; }
-  int32_t n_cols_at(int p) const { return nc[std::min<size_t>(static_cast<size_t>(p), nc.size()) - 1]; }
+  int32_t n_rows_at(int p) const { return rows.n[std::min<size_t>(static_cast<size_t>(p), rows.n.size()) - 1]; }
+  int32_t n_cols_at(int p) const { return cols->n[std::min<size_t>(static_cast<size_t>(p), cols->n.size()) - 1]; }
 };
 
-prefix_classes classes_of_grid(const std::vector<double> &lin, const std::vector<double> &ang, double vx0, double vth0,
-                               double acc_x, double acc_theta, double dt, int S) {
-  prefix_classes pc;
-  pc.max_p = std::min(S - 1, 48);
-  velocity_classes(lin, vx0, acc_x, dt, pc.max_p, pc.rc, pc.nr);
-  velocity_classes(ang, vth0, acc_theta, dt, pc.max_p, pc.cc, pc.nc);
-  return pc;
+void classes_of_grid(prefix_classes &pc, const std::vector<double> &lin, const std::vector<double> &ang, double vx0,
+                     double vth0, double acc_x, double acc_theta, double dt, int S, const axis_classes *shared_cols = nullptr) {
+  pc.max_p = prefix_max_p(S);
+  pc.rows = classes_of_axis(lin, vx0, acc_x, dt, pc.max_p);
+  if (shared_cols && shared_cols->made_for(ang, vth0, acc_theta, dt, pc.max_p)) {
+    pc.cols = shared_cols;
+  } else {
+    pc.own_cols = classes_of_axis(ang, vth0, acc_theta, dt, pc.max_p);
+    pc.cols = &pc.own_cols;
+  }
 }
 
 // The levels' end steps.  A level ending at step p costs (p - q) steps over classes(p) items plus a
@@ -354,7 +394,7 @@ prefix_classes classes_of_grid(const std::vector<double> &lin, const std::vector
 std::vector<int> choose_levels(const prefix_classes &pc, int64_t T, int S, double samples_per_wave) {
   std::vector<int> steps;
   const double full = step_cost(static_cast<double>(T), samples_per_wave);
-  const int last_p = std::min<int>(pc.max_p, static_cast<int>(std::max(pc.nr.size(), pc.nc.size())));
+  const int last_p = std::min<int>(pc.max_p, static_cast<int>(std::max(pc.rows.n.size(), pc.cols->n.size())));
   std::vector<double> best(static_cast<size_t>(last_p) + 1, 0.0);
   std::vector<int> from(static_cast<size_t>(last_p) + 1, 0);
   double best_total = S * full;
@@ -390,10 +430,11 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   if (!forced && T < 4096) return SFW_OK;  // the GPU is not full: extra launches cost more than they save
   const int64_t rows_per_chunk = chunk / h->nw;
   if (rows_per_chunk < 1) return SFW_OK;  // a single row does not fit the table budget: no sharing
-  const prefix_classes pc = classes_of_grid(h->h_lin, h->h_ang, h->rs.vx, h->rs.vtheta, h->ga.acc_x, h->ga.acc_theta,
-                                            h->params.sim_time / S, S);
-  const std::vector<std::vector<int32_t>> &rc = pc.rc, &cc = pc.cc;
-  const std::vector<int32_t> &nr = pc.nr, &nc = pc.nc;
+  prefix_classes pc;
+  classes_of_grid(pc, h->h_lin, h->h_ang, h->rs.vx, h->rs.vtheta, h->ga.acc_x, h->ga.acc_theta, h->params.sim_time / S, S,
+                  static_cast<const axis_classes *>(h->shared_cols));
+  const std::vector<std::vector<int32_t>> &rc = pc.rc(), &cc = pc.cc();
+  const std::vector<int32_t> &nr = pc.rows.n, &nc = pc.cols->n;
   auto level = [](const std::vector<std::vector<int32_t>> &c, int p) -> const std::vector<int32_t> & {
     return c[std::min<size_t>(static_cast<size_t>(p), c.size()) - 1];
   };
@@ -562,6 +603,12 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   if (!rs || !lin || !ang || !args || nv <= 0 || nw <= 0)
     return fail(h, SFW_ERR_INVALID_ARG, "grid_stage: null pointer or non-positive sample count");
   if (!h->have_costmap) return fail(h, SFW_ERR_STATE, "grid_stage: no costmap set (sfw_set_costmap)");
+  // A NaN would come back as a NaN cost (the header promises sentinels, never NaN) and, in a sample vector, break the
+  // ordering the shared-prefix planner sorts by: O(nv + nw) checks
+  if (!all_finite(&rs->x, 6) || !all_finite(&args->acc_x, 5) || !std::isfinite(vy_samp))
+    return fail(h, SFW_ERR_INVALID_ARG, "grid_stage: non-finite robot state, goal argument or sample velocity");
+  if (!all_finite(lin, static_cast<size_t>(nv)) || !all_finite(ang, static_cast<size_t>(nw)))
+    return fail(h, SFW_ERR_INVALID_ARG, "grid_stage: non-finite sample velocity");
   SFW_HIP(h, hipSetDevice(h->device));
   h->h_lin.assign(lin, lin + nv);
   h->h_ang.assign(ang, ang + nw);
@@ -660,7 +707,11 @@ int launch_common(sfw_handle h) {
   const bool prefix = !h->prefix_steps.empty() && h->prefix_S == S && h->prefix_chunk <= chunk;
   if (prefix) chunk = h->prefix_chunk;
   const bool timing = h->timing;
-  if (timing) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  if (timing) {
+    SFW_HIP(h, h->clock.reserve(4));
+    SFW_HIP(h, hipMemsetAsync(h->clock.p, 0, 4 * sizeof(unsigned long long), h->stream));
+    SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  }
   const bool single = chunk >= T;
   h->n_chunks = static_cast<int>((T + chunk - 1) / chunk);
   if (!single && timing) {
@@ -675,6 +726,7 @@ int launch_common(sfw_handle h) {
     const int64_t n = (T - b < chunk) ? (T - b) : chunk;
     sfw_launch L;
     fill_launch(h, L, b, n, chunk);
+    L.clock_probe = timing ? h->clock.p : nullptr;  // every K2 dispatch writes it; the last one (the launch over the samples) stays
     if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c], h->stream));
     if (prefix) {
       // K1a -> { K2 prefix phase on the main stream  ||  K1b + K1c on the side stream } -> K2 suffix phase.
@@ -854,6 +906,7 @@ int sfw_destroy(sfw_handle h) {
   h->frame.release();
   h->fcode.release();
   h->partials.release();
+  h->clock.release();
   h->points.release();
   h->n_points.release();
   h->one_out.release();
@@ -927,6 +980,22 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   if (!h) return SFW_ERR_INVALID_ARG;
   if (A < 0 || O < 0 || (A > 0 && !agents) || (O > 0 && !obstacles_xy))
     return fail(h, SFW_ERR_INVALID_ARG, "set_agents: bad arguments");
+  for (int i = 0; i < A; ++i) {
+    const sfw_agent &a = agents[i];
+    if (!all_finite(&a.x, 4) || !std::isfinite(a.desired_velocity) || !std::isfinite(a.radius) ||
+        (a.has_goal && !(all_finite(&a.goal_x, 2) && std::isfinite(a.goal_radius))))
+      return fail(h, SFW_ERR_INVALID_ARG, "set_agents: non-finite field in agent " + std::to_string(i));
+    // A person that may never move (speed clamp to 0, lightsfm updatePosition) stays at exact relative rest with every
+    // other such person — and with a stopped robot — at EVERY step, where the reference's interaction angle is libm
+    // rounding noise (see rest_forces): only the handed-over state is covered by the host-evaluated terms
+    if (i > 0 && !(a.desired_velocity > 0.0))
+      return fail(h, SFW_ERR_UNSUPPORTED, "set_agents: person " + std::to_string(i) + " has desired_velocity <= 0 (include/sfw_hip.h, sfw_agent)");
+  }
+  if (O > 0 && !all_finite(obstacles_xy, 2 * static_cast<size_t>(O)))
+    return fail(h, SFW_ERR_INVALID_ARG, "set_agents: non-finite laser point");
+  // The flat K2 addresses an agent's LDS words through 16-bit byte offsets (pair table) and the whole set has to fit one
+  // wave's LDS allocation long before that: refused here, not as a failed launch later
+  if (A > 8190) return fail(h, SFW_ERR_UNSUPPORTED, "set_agents: more than 8190 agents");
   const size_t An = static_cast<size_t>(A > 0 ? A : 1), On = static_cast<size_t>(O > 0 ? O : 1);
   // groups: dense index in order of first appearance, CSR member lists in agent order
   std::vector<int32_t> grp(An, -1), ids, off(1, 0), mem;
@@ -982,14 +1051,36 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   h->n_grp_mem = n_mem;
   h->A = A;
   h->O = O;
+  // pairs with equal velocities (v_i - v_j == 0 in both components; -0.0 equals +0.0): agents ordered by velocity, the
+  // pairs inside each run of equal velocities — O(A log A) on the control-cycle path instead of all A^2 / 2 compares
   h->rest_pairs.clear();
-  for (int i = 0; i < A; ++i)
-    for (int j = i + 1; j < A; ++j)
-      if (agents[i].vx - agents[j].vx == 0.0 && agents[i].vy - agents[j].vy == 0.0 &&
-          !(agents[i].x == agents[j].x && agents[i].y == agents[j].y)) {
-        h->rest_pairs.emplace_back(i, j);
-        h->rest_pairs.emplace_back(j, i);
+  std::vector<int32_t> order(static_cast<size_t>(A));
+  for (int i = 0; i < A; ++i) order[static_cast<size_t>(i)] = i;
+  auto vkey = [&](int32_t i) { return std::make_pair(agents[i].vx + 0.0, agents[i].vy + 0.0); };  // x + 0.0: -0.0 -> +0.0
+  std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+    const auto ka = vkey(a), kb = vkey(b);
+    return ka != kb ? ka < kb : a < b;
+  });
+  for (size_t b = 0; b < order.size();) {
+    size_t e = b + 1;
+    while (e < order.size() && vkey(order[e]) == vkey(order[b])) ++e;
+    for (size_t x = b; x < e; ++x)
+      for (size_t y = x + 1; y < e; ++y) {
+        const int32_t i = order[x], j = order[y];  // i < j: runs are in index order
+        if (!(agents[i].x == agents[j].x && agents[i].y == agents[j].y)) {
+          h->rest_pairs.emplace_back(i, j);
+          h->rest_pairs.emplace_back(j, i);
+        }
       }
+    b = e;
+  }
+  // rest_forces adds a pair's term to its first agent in list order: keep the order of the all-pairs scan (i ascending,
+  // then j), so that an agent's sum is rounded as before
+  std::sort(h->rest_pairs.begin(), h->rest_pairs.end(), [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) {
+    const auto ka = std::make_pair(std::min(a.first, a.second), std::max(a.first, a.second));
+    const auto kb = std::make_pair(std::min(b.first, b.second), std::max(b.first, b.second));
+    return ka != kb ? ka < kb : a.first < b.first;
+  });
   return SFW_OK;
 }
 
@@ -1086,7 +1177,8 @@ int sfw_plan_shared_prefix(const double *linvels, int32_t nv, const double *angv
   const int64_t T = static_cast<int64_t>(nv) * nw;
   if (n_agents < 2 || num_steps < 2 || T < 4096) return SFW_OK;
   const std::vector<double> lin(linvels, linvels + nv), ang(angvels, angvels + nw);
-  const prefix_classes pc = classes_of_grid(lin, ang, vx0, vtheta0, acc_x, acc_theta, sim_time / num_steps, num_steps);
+  prefix_classes pc;
+  classes_of_grid(pc, lin, ang, vx0, vtheta0, acc_x, acc_theta, sim_time / num_steps, num_steps);
   const std::vector<int> steps = choose_levels(pc, T, num_steps, static_cast<double>(sfw_samples_per_wave(n_agents, T, SFW_K2_AUTO)));
   *n_levels = static_cast<int32_t>(steps.size());
   for (size_t l = 0; l < steps.size() && l < static_cast<size_t>(cap); ++l) {
@@ -1157,6 +1249,22 @@ int sfw_last_launch_ms(sfw_handle h, int32_t which, float *ms_out) {
     default: return fail(h, SFW_ERR_INVALID_ARG, "last_launch_ms: which must be 0..3");
   }
   SFW_HIP(h, hipEventElapsedTime(ms_out, h->ev[a], h->ev[b]));
+  return SFW_OK;
+}
+
+int sfw_last_clock_ghz(sfw_handle h, double *ghz_out) {
+  if (!h || !ghz_out) return SFW_ERR_INVALID_ARG;
+  if (!h->launched) return fail(h, SFW_ERR_STATE, "last_clock_ghz before grid_launch");
+  if (!h->launched_timed) return fail(h, SFW_ERR_STATE, "last_clock_ghz: timing was off for the last launch (sfw_set_timing)");
+  SFW_HIP(h, hipSetDevice(h->device));
+  SFW_HIP(h, hipEventSynchronize(h->ev[3]));
+  unsigned long long v[4] = {0, 0, 0, 0};
+  SFW_HIP(h, hipMemcpy(v, h->clock.p, sizeof(v), hipMemcpyDeviceToHost));
+  int wall_khz = 0;
+  SFW_HIP(h, hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, h->device));
+  *ghz_out = 0.0;  // no sample: no agents, or wave 0 had nothing to integrate
+  if (v[2] > v[0] && v[3] > v[1] && wall_khz > 0)
+    *ghz_out = static_cast<double>(v[2] - v[0]) / static_cast<double>(v[3] - v[1]) * wall_khz * 1e-6;
   return SFW_OK;
 }
 
@@ -1252,22 +1360,32 @@ void *sfw_stream(sfw_handle h) { return h ? static_cast<void *>(h->stream) : nul
 // one process, several devices (sfw_multi_*)
 // ===========================================================================
 namespace {
-// librccl.so, resolved on first use: a single-device caller never loads it
+// The six RCCL entry points this file uses, declared here (values as in <rccl/rccl.h> of ROCm 7.2, NCCL 2.x ABI) so
+// that the library builds on a ROCm install without the rccl development package and a single-device caller never
+// needs librccl at all: it is resolved with dlopen on the first sfw_multi_create(SFW_MULTI_RCCL).
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr int ncclDouble = 8;  // ncclDataType_t: ncclFloat64
+constexpr int ncclMin = 3;     // ncclRedOp_t
 struct rccl_api {
   void *lib = nullptr;
+  std::string error;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
-  std::string load() {
-    if (lib) return "";
+  void load_once() {
     for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
       lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (lib) break;
     }
-    if (!lib) return std::string("cannot load librccl.so: ") + dlerror();
+    if (!lib) {
+      error = std::string("cannot load librccl.so: ") + dlerror();
+      return;
+    }
     auto sym = [&](const char *n) { return dlsym(lib, n); };
     CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
@@ -1278,12 +1396,87 @@ struct rccl_api {
     if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd || !GetErrorString) {
       dlclose(lib);
       lib = nullptr;
-      return "librccl.so lacks ncclCommInitAll/ncclAllReduce/ncclGroupStart/...";
+      error = "librccl.so lacks ncclCommInitAll/ncclAllReduce/ncclGroupStart/...";
     }
-    return "";
   }
+  // "" or why RCCL is not available; safe from several threads (two planners created concurrently)
+  const std::string &load() {
+    std::call_once(once, [this] { load_once(); });
+    return error;
+  }
+  std::once_flag once;
 };
 rccl_api g_rccl;
+
+// One worker thread per rank of a multi handle, alive for the handle's lifetime: a rank's stage + launch is ~100 us
+// of host work (shared-prefix planning, one H2D copy, a dozen kernel launches) and the ranks are independent, so a
+// grid cut R ways is enqueued in the time of one rank instead of R.  run() hands every worker its job and returns
+// when all are done.
+struct rank_workers {
+  struct slot {
+    std::thread th;
+    std::function<int()> job;
+    bool has_job = false, quit = false;
+    int rc = 0;
+  };
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::vector<slot> w;
+  int pending = 0;
+  void start(int R) {
+    w.resize(static_cast<size_t>(R));
+    for (int r = 0; r < R; ++r) w[static_cast<size_t>(r)].th = std::thread([this, r] { loop(r); });
+  }
+  void loop(int r) {
+    slot &me = w[static_cast<size_t>(r)];
+    for (;;) {
+      std::function<int()> job;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_job.wait(lk, [&] { return me.has_job || me.quit; });
+        if (me.quit) return;
+        job = std::move(me.job);
+        me.has_job = false;
+      }
+      const int rc = job();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        me.rc = rc;
+        if (--pending == 0) cv_done.notify_all();
+      }
+    }
+  }
+  // jobs[r] runs on worker r; returns the first non-zero result (by rank), or 0
+  int run(std::vector<std::function<int()>> &jobs, int *failed_rank) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      pending = static_cast<int>(jobs.size());
+      for (size_t r = 0; r < jobs.size(); ++r) {
+        w[r].job = std::move(jobs[r]);
+        w[r].has_job = true;
+      }
+    }
+    cv_job.notify_all();
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+    for (size_t r = 0; r < w.size(); ++r)
+      if (w[r].rc != 0) {
+        if (failed_rank) *failed_rank = static_cast<int>(r);
+        return w[r].rc;
+      }
+    return 0;
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (slot &s : w) s.quit = true;
+    }
+    cv_job.notify_all();
+    for (slot &s : w)
+      if (s.th.joinable()) s.th.join();
+    w.clear();
+  }
+};
 }  // namespace
 
 struct sfw_multi_s {
@@ -1300,6 +1493,8 @@ struct sfw_multi_s {
   bool scored = false;
   double us[3] = {0, 0, 0};
   std::string err;
+  rank_workers workers;               // R > 1 only
+  std::vector<std::string> rank_err;  // what went wrong on a rank's worker (its handle's message, or a HIP error)
 };
 
 #define SFW_MHIP(m, h, call)                                                                  \
@@ -1341,6 +1536,7 @@ int sfw_multi_create(const sfw_params *params, const int *devices, int32_t R, in
   m->exchange = exchange;
   m->dev.assign(devices, devices + R);
   m->d_table.assign(static_cast<size_t>(R), nullptr);
+  m->rank_err.assign(static_cast<size_t>(R), "");
   int rc = SFW_OK;
   for (int r = 0; r < R && rc == SFW_OK; ++r) {
     sfw_handle h = nullptr;
@@ -1355,8 +1551,7 @@ int sfw_multi_create(const sfw_params *params, const int *devices, int32_t R, in
   if (rc == SFW_OK && hipHostMalloc(reinterpret_cast<void **>(&m->pin_table), sizeof(double) * 5 * R, hipHostMallocDefault) != hipSuccess)
     rc = SFW_ERR_HIP;
   if (rc == SFW_OK && exchange == SFW_MULTI_RCCL) {
-    const std::string e = g_rccl.load();
-    if (!e.empty()) rc = SFW_ERR_UNSUPPORTED;
+    if (!g_rccl.load().empty()) rc = SFW_ERR_UNSUPPORTED;
     else {
       m->comm.assign(static_cast<size_t>(R), nullptr);
       const ncclResult_t nr = g_rccl.CommInitAll(m->comm.data(), R, devices);
@@ -1370,12 +1565,14 @@ int sfw_multi_create(const sfw_params *params, const int *devices, int32_t R, in
     sfw_multi_destroy(m);
     return rc;
   }
+  if (R > 1) m->workers.start(R);
   *out = m;
   return SFW_OK;
 }
 
 int sfw_multi_destroy(sfw_multi_handle m) {
   if (!m) return SFW_OK;
+  m->workers.stop();
   for (size_t r = 0; r < m->h.size(); ++r) (void)sfw_grid_sync(m->h[r]);
   for (ncclComm_t c : m->comm)
     if (c) (void)g_rccl.CommDestroy(c);
@@ -1438,24 +1635,66 @@ int sfw_multi_score_grid(sfw_multi_handle m, const sfw_robot_state *rs, const do
   m->row0.assign(static_cast<size_t>(R) + 1, 0);
   for (int r = 0; r <= R; ++r) m->row0[static_cast<size_t>(r)] = static_cast<int32_t>((static_cast<int64_t>(r) * nv) / R);  // ref :345: rows are the outer axis
   const double t0 = now_us();
-  // (1) every rank: stage its block of rows, enqueue the kernels and its row of the exchange table
+  // (0) what is the same for every rank, once: the agent set must fit a wave's LDS for every rank's item count
+  // before anything is launched anywhere, and the classes of the column axis (every rank scores all nw columns)
+  sfw_handle h0 = m->h[0];
   for (int r = 0; r < R; ++r) {
-    sfw_handle h = m->h[static_cast<size_t>(r)];
-    const int32_t lo = m->row0[static_cast<size_t>(r)], n = m->row0[static_cast<size_t>(r) + 1] - lo;
-    SFW_MHIP(m, h, hipSetDevice(m->dev[static_cast<size_t>(r)]));
-    if (n > 0) {
-      if (int e = sfw_grid_stage(h, rs, linvels + lo, n, angvels, nw, args, static_cast<int64_t>(lo) * nw))
-        return mrank_fail(m, r, e, "sfw_grid_stage");
-      if (int e = sfw_grid_launch(h)) return mrank_fail(m, r, e, "sfw_grid_launch");
-      if (sfw_launch_key_table(h->d_sel, m->d_table[static_cast<size_t>(r)], r, R, h->stream) != hipSuccess)
-        return mfail(m, SFW_ERR_HIP, "key table launch failed");
-    } else {  // fewer rows than ranks: this rank holds nothing, its row stays +inf / 0 valid
-      for (int e = 0; e < 5 * R; ++e) m->pin_table[e] = std::numeric_limits<double>::infinity();
-      m->pin_table[5 * r + 4] = 0.0;
-      if (hipMemcpyAsync(m->d_table[static_cast<size_t>(r)], m->pin_table, sizeof(double) * 5 * R, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-          hipStreamSynchronize(h->stream) != hipSuccess)
-        return mfail(m, SFW_ERR_HIP, "empty-rank table upload failed");
+    const int64_t items = static_cast<int64_t>(m->row0[static_cast<size_t>(r) + 1] - m->row0[static_cast<size_t>(r)]) * nw;
+    if (items > 0 && h0->A > 0 && sfw_social_lds_bytes(h0->A, h0->O, h0->NG, h0->n_grp_mem, items, h0->k2_form) > 160 * 1024)
+      return mfail(m, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
+  }
+  axis_classes cols;
+  const axis_classes *shared = nullptr;
+  {
+    const int S = num_steps_of(h0->params);
+    const int64_t rows_max = (nv + R - 1) / R;
+    if (R > 1 && h0->A >= 2 && S >= 2 && rows_max * nw >= 4096 && (h0->prefix_env.empty() || h0->prefix_env[0] != 0)) {
+      cols = classes_of_axis(m->ang, rs->vtheta, args->acc_theta, h0->params.sim_time / S, prefix_max_p(S));
+      shared = &cols;
     }
+  }
+  // (1) every rank: stage its block of rows, enqueue the kernels and its row of the exchange table
+  auto rank_job = [&](int r) -> int {
+    sfw_handle h = m->h[static_cast<size_t>(r)];
+    std::string &err = m->rank_err[static_cast<size_t>(r)];
+    err.clear();
+    const int32_t lo = m->row0[static_cast<size_t>(r)], n = m->row0[static_cast<size_t>(r) + 1] - lo;
+    hipError_t e = hipSetDevice(m->dev[static_cast<size_t>(r)]);
+    if (e != hipSuccess) {
+      err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+      return SFW_ERR_HIP;
+    }
+    if (n > 0) {
+      h->shared_cols = shared;
+      const int rc_stage = sfw_grid_stage(h, rs, linvels + lo, n, angvels, nw, args, static_cast<int64_t>(lo) * nw);
+      h->shared_cols = nullptr;
+      if (rc_stage) {
+        err = std::string("sfw_grid_stage: ") + sfw_last_error(h);
+        return rc_stage;
+      }
+      if (int rc = sfw_grid_launch(h)) {
+        err = std::string("sfw_grid_launch: ") + sfw_last_error(h);
+        return rc;
+      }
+    }
+    // fewer rows than ranks: this rank holds nothing, its row is +inf / 0 valid (null selection record)
+    e = sfw_launch_key_table(n > 0 ? h->d_sel : nullptr, m->d_table[static_cast<size_t>(r)], r, R, h->stream);
+    if (e != hipSuccess) {
+      err = std::string("key table launch: ") + hipGetErrorString(e);
+      return SFW_ERR_HIP;
+    }
+    return SFW_OK;
+  };
+  {
+    int failed = 0, rc = SFW_OK;
+    if (R == 1) {
+      rc = rank_job(0);
+    } else {
+      std::vector<std::function<int()>> jobs;
+      for (int r = 0; r < R; ++r) jobs.emplace_back([&rank_job, r] { return rank_job(r); });
+      rc = m->workers.run(jobs, &failed);
+    }
+    if (rc != SFW_OK) return mfail(m, rc, m->rank_err[static_cast<size_t>(failed)] + " (rank " + std::to_string(failed) + ")");
   }
   const double t1 = now_us();
   // (2) the exchange
@@ -1470,7 +1709,6 @@ int sfw_multi_score_grid(sfw_multi_handle m, const sfw_robot_state *rs, const do
     const ncclResult_t ne = g_rccl.GroupEnd();
     if (nr == ncclSuccess) nr = ne;
     if (nr != ncclSuccess) return mfail(m, SFW_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nr));
-    sfw_handle h0 = m->h[0];
     SFW_MHIP(m, h0, hipSetDevice(m->dev[0]));
     SFW_MHIP(m, h0, hipMemcpyAsync(m->pin_table, m->d_table[0], sizeof(double) * 5 * R, hipMemcpyDeviceToHost, h0->stream));
     SFW_MHIP(m, h0, hipStreamSynchronize(h0->stream));

@@ -466,6 +466,18 @@ __device__ __forceinline__ late_launch late_args() {
   return static_cast<late_launch>(p);  // sfw_launch is the first kernel argument: offset 0 of the segment
 }
 
+// Measurement aid (sfw_set_timing): wave 0 of a K2 launch records the shader-clock counter (s_memtime) and the
+// constant-rate counter (s_memrealtime) when it starts and when it ends; the host turns the two differences into the
+// clock the kernel sustained (boxes differ by ~10 %: a kernel time means little without it).  Written straight to
+// memory: nothing is held in registers across the rollout.
+__device__ __forceinline__ void clock_probe(int which) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  unsigned long long *const p = late_args()->clock_probe;
+  if (!p) return;
+  p[2 * which] = __builtin_readcyclecounter();
+  p[2 * which + 1] = wall_clock64();
+}
+
 // Social-force constants of the PAIR term in the force type (host-derived, see sfw_derived).
 template <typename R> struct sfm_consts {
   sfwm::poly_consts pc;
@@ -973,6 +985,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     if (L.phase == SFW_PHASE_PREFIX && lane < Gn) L.out_dead[first_local + lane] = s.dead[lane];
     return;
   }
+  clock_probe(0);
 
   // ---- this lane's slots --------------------------------------------------
   int sl_[NS], g_[NS], i_[NS];
@@ -1194,6 +1207,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         out_state[(first_local + g_[r]) * A + i_[r]] = c;
       }
     if (lane < Gn) Le->out_dead[first_local + lane] = s.dead[lane];
+    clock_probe(1);
     return;
   }
   double sw_acc = 0.0;
@@ -1203,6 +1217,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     else if (ok_[r]) s.swp[sl_[r]] = sw[r];
   }
   finish_wave(s, lane, G, Gn, first_local, sw_acc);
+  clock_probe(1);
 }
 
 // ---------------------------------------------------------------------------
@@ -1279,6 +1294,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     if (L.phase == SFW_PHASE_PREFIX && lane == 0) L.out_dead[first_local] = s.dead[0];
     return;
   }
+  clock_probe(0);
   const int64_t rsample = robot_sample_of_item(L, first_local);
 
   if (L.resume) {  // resume from the record of the item's (parent) class
@@ -1507,11 +1523,13 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       rec[sl] = c;
     }
     if (lane == 0) Le->out_dead[first_local] = s.dead[0];
+    clock_probe(1);
     return;
   }
   double sw_acc = 0.0;
   for (int sl = lane; sl < A; sl += WAVE) sw_acc += s.swp[sl];
   finish_wave(s, lane, 1, 1, first_local, sw_acc);
+  clock_probe(1);
 }
 
 // ===========================================================================
@@ -1603,7 +1621,7 @@ __global__ void __launch_bounds__(64) sfw_key_table_kernel(const sfw_sel *sel, d
   for (int e = threadIdx.x; e < 5 * R; e += blockDim.x) {
     double v = INFINITY;
     if (e / 5 == r) {
-      const sfw_sel s = *sel;
+      const sfw_sel s = sel ? *sel : sel_empty();  // null: a rank without rows (+inf key, 0 valid samples)
       const int c = e % 5;
       if (c == 4) v = static_cast<double>(s.n_valid);
       else if (isfinite(s.cost)) v = c == 0 ? s.cost : c == 1 ? s.neg_linvel : c == 2 ? s.abs_angvel : static_cast<double>(s.neg_index);

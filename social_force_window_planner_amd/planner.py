@@ -87,6 +87,7 @@ def lib():
         L.sfw_set_k2_form.argtypes = [vp, C.c_int32]
         L.sfw_set_timing.argtypes = [vp, C.c_int32]
         L.sfw_last_launch_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
+        L.sfw_last_clock_ghz.argtypes = [vp, C.POINTER(C.c_double)]
         L.sfw_grid_points.argtypes = [vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32)]
         L.sfw_grid_points_batch.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
         L.sfw_stream.argtypes = [vp]
@@ -241,6 +242,12 @@ class HipScorer:
         self._check(lib().sfw_last_launch_ms(self._h, which, C.byref(ms)), "sfw_last_launch_ms")
         return ms.value
 
+    def sustained_clock_ghz(self):
+        """Shader clock the last timed launch's social-force kernel ran at (0.0: nothing sampled)."""
+        v = C.c_double()
+        self._check(lib().sfw_last_clock_ghz(self._h, C.byref(v)), "sfw_last_clock_ghz")
+        return v.value
+
     def grid_points_batch(self, first, count, n_steps):
         """Trajectory points of `count` consecutive samples: (points[count, n_steps, 3], n_points[count])."""
         pts = np.zeros((count, n_steps, 3), dtype=np.float64)
@@ -255,6 +262,16 @@ class HipScorer:
         self._check(lib().sfw_grid_points(self._h, index, pts.ctypes.data, points_cap, C.byref(n)),
                     "sfw_grid_points")
         return pts[: min(n.value, points_cap)].copy()
+
+
+def plan_info_of_rank(multi, r):
+    """sfw_grid_plan_info of rank r's handle of a MultiScorer (after a score_grid)."""
+    info = SfwPlanInfo()
+    h = lib().sfw_multi_rank_handle(multi._m, r)
+    rc = lib().sfw_grid_plan_info(h, C.byref(info))
+    if rc != SFW_OK:
+        raise SfwError(rc, "sfw_grid_plan_info")
+    return info.as_dict()
 
 
 class MultiScorer:

@@ -137,3 +137,90 @@ def test_world_changes_between_stage_and_launch(oracle_mod, hip_mod):
     v = oc2 >= 0
     assert np.array_equal(oc2 < 0, c2 < 0) and np.max(np.abs(c2[v] - oc2[v]) / np.abs(oc2[v])) <= 1e-9
     assert b2["index"] == ob2["index"]
+
+
+def test_non_finite_inputs_are_refused(hip_mod):
+    """"never NaN" (include/sfw_hip.h) holds because NaN / Inf never get in: agents, laser points, robot state, goal
+    arguments and sample velocities are checked on the host (O(A + O + nv + nw)) and refused with
+    SFW_ERR_INVALID_ARG; the handle keeps working with its previous world state."""
+    L = hip_mod.lib()
+    scene = syn.make_scene("ref5x9")
+    g = hip_mod.HipScorer(default_params())
+    g.load_scene(scene)
+    c0, b0 = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    lin, ang = scene.linvels, scene.angvels
+    best = SfwBest()
+    n = len(scene.agents)
+    for field, bad in (("x", float("nan")), ("vy", float("inf")), ("radius", float("nan")),
+                       ("desired_velocity", float("-inf")), ("goal_x", float("nan"))):
+        agents = (SfwAgent * n)(*scene.agents)
+        setattr(agents[2], field, bad)
+        assert L.sfw_set_agents(g._h, C.addressof(agents), n, None, 0) == SFW_ERR_INVALID_ARG, field
+        assert b"agent 2" in L.sfw_last_error(g._h)
+    # a goal that is not there may hold anything
+    agents = (SfwAgent * n)(*scene.agents)
+    agents[2].has_goal, agents[2].goal_x = 0, float("nan")
+    assert L.sfw_set_agents(g._h, C.addressof(agents), n, None, 0) == SFW_OK
+    g.load_scene(scene)
+    obs = np.array([[1.0, 2.0], [float("nan"), 0.0]])
+    assert L.sfw_set_agents(g._h, C.addressof(scene.agents), n, obs.ctypes.data, 2) == SFW_ERR_INVALID_ARG
+    ga = SfwGoalArgs(*scene.goal_args)
+    for k in range(6):
+        v = list(scene.robot_state)
+        v[k] = float("nan")
+        rs = SfwRobotState(*v)
+        assert L.sfw_score_grid(g._h, C.byref(rs), lin.ctypes.data, 5, ang.ctypes.data, 9, C.byref(ga), None,
+                                C.byref(best)) == SFW_ERR_INVALID_ARG
+    rs = SfwRobotState(*scene.robot_state)
+    gbad = SfwGoalArgs(*scene.goal_args)
+    gbad.wpx = float("inf")
+    assert L.sfw_score_grid(g._h, C.byref(rs), lin.ctypes.data, 5, ang.ctypes.data, 9, C.byref(gbad), None, None) == SFW_ERR_INVALID_ARG
+    lbad = lin.copy()
+    lbad[3] = float("nan")
+    assert L.sfw_score_grid(g._h, C.byref(rs), lbad.ctypes.data, 5, ang.ctypes.data, 9, C.byref(ga), None, None) == SFW_ERR_INVALID_ARG
+    # a NaN in a large sample vector reaches the shared-prefix planner's sort in no case (ADVICE r2)
+    big_l, big_a = syn.generalised_sampler(96, 96)
+    big_a = big_a.copy()
+    big_a[50] = float("nan")
+    assert L.sfw_grid_stage(g._h, C.byref(rs), big_l.ctypes.data, 96, big_a.ctypes.data, 96, C.byref(ga), 0) == SFW_ERR_INVALID_ARG
+    cost = C.c_double()
+    assert L.sfw_score_one(g._h, C.byref(rs), 0.3, float("nan"), 0.1, C.byref(ga), C.byref(cost), None, 0, None) == SFW_ERR_INVALID_ARG
+    c1, b1 = g.score_grid(scene.robot_state, lin, ang, scene.goal_args)
+    assert np.array_equal(c0, c1) and b0 == b1 and np.all(np.isfinite(c1))
+
+
+def test_unsupported_agent_sets(hip_mod):
+    """What the device cannot (or, for parity, must not) take is SFW_ERR_UNSUPPORTED, not a failed launch: more agents
+    than one wave's LDS holds, more than the 16-bit plane offsets of the pair table reach, and a person that can never
+    move (desired_velocity <= 0: at exact relative rest with its like at every step)."""
+    from social_force_window_planner_amd.planner import SfwError
+
+    L = hip_mod.lib()
+    scene = syn.make_scene("ref5x9")
+    g = hip_mod.HipScorer(default_params())
+    g.load_scene(scene)
+    n = len(scene.agents)
+    agents = (SfwAgent * n)(*scene.agents)
+    agents[3].desired_velocity = 0.0
+    assert L.sfw_set_agents(g._h, C.addressof(agents), n, None, 0) == SFW_ERR_UNSUPPORTED
+    assert b"desired_velocity" in L.sfw_last_error(g._h)
+    agents[3].desired_velocity = 1.0
+    agents[0].desired_velocity = 0.0  # the robot is not integrated by the social-force model: anything goes
+    assert L.sfw_set_agents(g._h, C.addressof(agents), n, None, 0) == SFW_OK
+    for count, where in ((9000, "set_agents"), (3000, "launch")):
+        many = (SfwAgent * count)()
+        for i in range(count):
+            a = many[i]
+            a.x, a.y, a.vx, a.vy = 3.0 + 0.001 * i, 2.0 + 0.0013 * (i % 97), 0.1, 1e-5 * i
+            a.goal_x, a.goal_y, a.goal_radius, a.desired_velocity, a.radius, a.has_goal, a.id, a.group_id = 9.0, 9.0, 0.35, 1.0, 0.35, 1, i, -1
+        rc = L.sfw_set_agents(g._h, C.addressof(many), count, None, 0)
+        if where == "set_agents":
+            assert rc == SFW_ERR_UNSUPPORTED
+        else:
+            assert rc == SFW_OK
+            with pytest.raises(SfwError) as e:
+                g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+            assert e.value.status == SFW_ERR_UNSUPPORTED and "LDS" in str(e.value)
+    g.load_scene(scene)
+    c, b = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert (c >= 0).any()

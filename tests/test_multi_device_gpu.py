@@ -44,6 +44,85 @@ def test_multi_equals_single(hip_mod, devices, exchange, nv, nw):
         assert np.array_equal(m.grid_points(idx), g.grid_points(idx))
 
 
+@pytest.mark.parametrize("nv,nw,R", [(256, 64, 4), (64, 256, 8), (130, 96, 8), (5, 9, 8)])
+def test_many_ranks_share_the_column_plan(hip_mod, nv, nw, R):
+    """R = 4 / 8 ranks staged and launched by the handle's worker threads, the shared-prefix classes of the column
+    axis computed once for all of them (256 x 64 over 4 ranks: 4096 samples per rank, every rank plans a prefix
+    tree): costs, selection and plan-dependent results bit-equal to one sfw_score_grid; 5 rows over 8 ranks: three
+    ranks hold nothing."""
+    scene = _scene(nv, nw, n_people=12, seed=72)
+    p = default_params()
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    c1, b1 = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    m = hip_mod.MultiScorer(p, devices=(0,) * R, exchange=SFW_MULTI_HOST_REDUCE)
+    m.load_scene(scene)
+    for _ in range(3):  # the workers are reused call after call
+        c2, b2 = m.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+        assert np.array_equal(c1, c2) and b1 == b2
+    if (nv // R) * nw >= 4096:
+        info = hip_mod.plan_info_of_rank(m, 1)
+        assert info["levels"] > 0
+    # another robot state and another column axis: the lent column classes must not outlive their call
+    rs2 = (0.0, 0.0, 0.0, float(np.float32(0.1)), 0.0, float(np.float32(0.2)))
+    ang2 = scene.angvels[::-1].copy()
+    c3, b3 = g.score_grid(rs2, scene.linvels, ang2, scene.goal_args)
+    c4, b4 = m.score_grid(rs2, scene.linvels, ang2, scene.goal_args)
+    assert np.array_equal(c3, c4) and b3 == b4
+
+
+def test_two_multi_planners_created_concurrently(hip_mod):
+    """librccl is resolved once however many threads create their first RCCL planner at the same time."""
+    import threading
+
+    scene = _scene(12, 9)
+    p = default_params()
+    g = hip_mod.HipScorer(p)
+    g.load_scene(scene)
+    c1, b1 = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    out = [None, None]
+
+    def work(k):
+        m = hip_mod.MultiScorer(p, devices=(0,), exchange=SFW_MULTI_RCCL)
+        m.load_scene(scene)
+        out[k] = m.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+        m.close()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for c, b in out:
+        assert np.array_equal(c, c1) and b == b1
+
+
+def test_multi_checks_the_lds_budget_before_any_rank_launches(hip_mod):
+    """An agent set that does not fit one wave's LDS is refused for the whole grid up front (SFW_ERR_UNSUPPORTED),
+    not after some ranks have been launched."""
+    from social_force_window_planner_amd._abi import SFW_ERR_UNSUPPORTED, SfwAgent
+    from social_force_window_planner_amd.planner import SfwError
+
+    scene = _scene(8, 9)
+    n = 3000
+    agents = (SfwAgent * n)()
+    for i in range(n):
+        a = agents[i]
+        a.x, a.y, a.vx, a.vy = 3.0 + 0.01 * i, 2.0 + 0.013 * (i % 97), 0.1, 0.001 * i
+        a.goal_x, a.goal_y, a.goal_radius, a.desired_velocity, a.radius, a.has_goal, a.id, a.group_id = 9.0, 9.0, 0.35, 1.0, 0.35, 1, i, -1
+    scene.agents = agents
+    m = hip_mod.MultiScorer(default_params(), devices=(0, 0), exchange=SFW_MULTI_HOST_REDUCE)
+    m.load_scene(scene)
+    with pytest.raises(SfwError) as e:
+        m.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert e.value.status == SFW_ERR_UNSUPPORTED and "LDS" in str(e.value)
+    g = hip_mod.HipScorer(default_params())
+    g.load_scene(scene)
+    with pytest.raises(SfwError) as e:
+        g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert e.value.status == SFW_ERR_UNSUPPORTED
+
+
 def test_multi_tie_across_ranks_and_all_invalid(hip_mod):
     """A full tie between samples of different ranks must resolve as in one launch (later iterate wins), and a
     grid without a selectable sample returns index -1 with the summed n_valid."""
