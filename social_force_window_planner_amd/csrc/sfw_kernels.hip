@@ -537,9 +537,9 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   const R ix = fma(k.lambda, wx, ux), iy = fma(k.lambda, wy, uy);
   const R l2 = fma(ix, ix, fma(iy, iy, tiny));
   rsqrt_sqrt(l2, rl, il);
-  const R sn = fma(ix, uy, -(iy * ux));  // |I| sin(theta)
-  const R cs = fma(ix, ux, iy * uy);     // |I| cos(theta)
-  const R theta = atan2_abs(k.pc, fabs(sn), cs, il);  // |(sn,cs)| = |I| since dhat is unit
+  const R sn = fma(ix, uy, -(iy * ux));    // |I| sin(theta)
+  const R ncs = fma(-ix, ux, -(iy * uy));  // -|I| cos(theta)
+  const R theta = angle_abs(k.pc, fabs(sn), ncs, rl, il);  // |(sn,cs)| = |I| since dhat is unit
   // ln Fs - |diff| / B: the force factor rides in the exponent (Fs exp(x) = exp(x + ln Fs)), clamped so that
   // exp_fast's integer exponent stays in range for any input (exp(-800) is 0 in double and in float; the clamp
   // never changes a result)

@@ -1,6 +1,6 @@
 // sfw_math.h — device math for the social-force pair term, written for the
 // gfx950 vector ALU: no special-case branches, hardware rcp/rsq seeds refined by
-// one Newton step, short Horner polynomials.  Accuracy targets: double ~1e-14
+// one Newton step, short Horner polynomials.  Accuracy targets: double ~1e-12
 // relative (the parity tests hold the whole path to 1e-9), float ~1e-7.
 // Coefficients: tools/gen_poly.py.
 #ifndef SFW_MATH_H_
@@ -10,16 +10,49 @@
 
 namespace sfwm {
 
-// 2*atan(t) = t * P(t*t), t = tan(phi/2) in [0, tan(pi/8)]; max abs err 1.9e-14
-__device__ constexpr double kAtanP[9] = {
-    1.99999999999994338e+00, -6.66666666614657344e-01, 3.99999991952324219e-01,
-    -2.85713802188508836e-01, 2.22207562443480111e-01, -1.81566154891948661e-01,
-    1.51262571875266205e-01, -1.17449017943713832e-01, 6.12649577079956778e-02};
-// exp(r), |r| <= ln2/2; max rel err 1.8e-14
+// Degrees of the two f64 polynomials of the pair term (tuning knobs, csrc/Makefile EXTRA; tools/gen_poly.py prints the
+// coefficient sets and their errors).  Every VALU instruction of the pair loop costs one 4-cycle issue slot, so a degree
+// is an issue slot per evaluation: asin 7 / exp 8 keep the pair term at ~1e-12 relative — the parity tests hold the whole
+// rollout to 1e-9, the north star asks for 1e-4.
+#ifndef SFW_ASIN_DEG
+#define SFW_ASIN_DEG 7
+#endif
+#ifndef SFW_EXP_DEG
+#define SFW_EXP_DEG 8
+#endif
+// asin(n) = n * Q(n*n), |n| <= sin(pi/8)
+#if SFW_ASIN_DEG == 8  // max abs err 2.3e-15
+__device__ constexpr double kAsinQ[9] = {
+    1.00000000000000266e+00, 1.66666666662883378e-01, 7.50000007366493221e-02, 4.46428039656598177e-02, 3.03838357891550621e-02,
+    2.23348546026741132e-02, 1.77785509266840877e-02, 1.12009038561371455e-02, 2.06905183025598710e-02};
+#elif SFW_ASIN_DEG == 7  // max abs err 5.4e-14
+__device__ constexpr double kAsinQ[8] = {
+    9.99999999999873768e-01, 1.66666666776879580e-01, 7.49999842884431500e-02, 4.46437065808175729e-02,
+    3.03595339518422935e-02, 2.26899347940125971e-02, 1.49057938849694732e-02, 2.32986453124961607e-02};
+#elif SFW_ASIN_DEG == 6  // max abs err 1.6e-12
+__device__ constexpr double kAsinQ[7] = {
+    1.00000000000385847e+00, 1.66666664088492733e-01, 7.50002798152002437e-02, 4.46315408500555302e-02,
+    3.05977872550623718e-02, 2.02964541344591819e-02, 2.68224190000059641e-02};
+#else
+#error "SFW_ASIN_DEG must be 6, 7 or 8"
+#endif
+// exp(r), |r| <= ln2/2
+#if SFW_EXP_DEG == 9  // max rel err 1.8e-14
 __device__ constexpr double kExpP[10] = {
     1.00000000000001421e+00, 1.00000000000000777e+00, 4.99999999994189259e-01, 1.66666666665346158e-01,
     4.16666670498183830e-02, 8.33333339452756693e-03, 1.38888004009164279e-03, 1.98411575417668925e-04,
     2.48850574964862367e-05, 2.76457905540610794e-06};
+#elif SFW_EXP_DEG == 8  // max rel err 1.1e-12
+__device__ constexpr double kExpP[9] = {
+    9.99999999999999667e-01, 9.99999999979770404e-01, 4.99999999998101408e-01, 1.66666668911656046e-01, 4.16666668852581981e-02,
+    8.33326607422800632e-03, 1.38888225044999920e-03, 1.99158800697442654e-04, 2.48757945821630479e-05};
+#elif SFW_EXP_DEG == 7  // max rel err 5.5e-11
+__device__ constexpr double kExpP[8] = {
+    9.99999999959529706e-01, 9.99999999995510036e-01, 5.00000010779330650e-01, 1.66666667863487161e-01,
+    4.16662181408892149e-02, 8.33328352427055441e-03, 1.39485902239979385e-03, 1.99075799133105149e-04};
+#else
+#error "SFW_EXP_DEG must be 7, 8 or 9"
+#endif
 // float 2*atan(t) = t * P(t*t); max abs err 1.4e-8 + float rounding
 __device__ constexpr float kAtanPf[5] = {1.999999963e+00f, -6.666557114e-01f, 3.994815087e-01f, -2.769682950e-01f, 1.595208338e-01f};
 
@@ -46,14 +79,14 @@ __device__ __forceinline__ float vgpr_const(float c) {
 // A VOP3 instruction reads at most one SGPR operand, so the first Horner step fma(c_n, z, c_{n-1}) of a chain
 // with both coefficients in SGPRs costs an extra v_mov_b64 per evaluation: the leading coefficients live in VGPRs.
 struct poly_consts {
-  double at[9], ex[10];
+  double as[SFW_ASIN_DEG + 1], ex[SFW_EXP_DEG + 1];
   __device__ __forceinline__ poly_consts() {
 #pragma unroll
-    for (int n = 0; n < 8; ++n) at[n] = sgpr_const(kAtanP[n]);
-    at[8] = vgpr_const(kAtanP[8]);
+    for (int n = 0; n < SFW_ASIN_DEG; ++n) as[n] = sgpr_const(kAsinQ[n]);
+    as[SFW_ASIN_DEG] = vgpr_const(kAsinQ[SFW_ASIN_DEG]);
 #pragma unroll
-    for (int n = 0; n < 9; ++n) ex[n] = sgpr_const(kExpP[n]);
-    ex[9] = vgpr_const(kExpP[9]);
+    for (int n = 0; n < SFW_EXP_DEG; ++n) ex[n] = sgpr_const(kExpP[n]);
+    ex[SFW_EXP_DEG] = vgpr_const(kExpP[SFW_EXP_DEG]);
   }
 };
 // v_rsq_f64 / v_rcp_f64 deliver ~23 good bits; one Newton step gives ~46.
@@ -81,26 +114,35 @@ __device__ __forceinline__ double exp_fast(const poly_consts &pc, double x) {
   const double t = fma(x, 1.4426950408889634074, shift);
   const double k = t - shift;
   const double r = fma(k, -6.93147180559945286227e-01, x);
-  double p = pc.ex[9];
+  double p = pc.ex[SFW_EXP_DEG];
 #pragma unroll
-  for (int n = 8; n >= 0; --n) p = fma(p, r, pc.ex[n]);
+  for (int n = SFW_EXP_DEG - 1; n >= 0; --n) p = fma(p, r, pc.ex[n]);
   return __builtin_amdgcn_ldexp(p, __double2loint(t));
 }
-// |atan2(y, x)| for y >= 0, result in [0, pi]; hyp = sqrt(x*x + y*y) > 0 (the
-// caller has it already).  Octant fold to phi in [0, pi/4], then the half-angle
-// t = tan(phi/2) = min / (max + hyp) in [0, tan(pi/8)] keeps the polynomial short.
-__device__ __forceinline__ double atan2_abs(const poly_consts &pc, double y, double x, double hyp) {
-  const double ax = fabs(x);
-  const double mn = fmin(y, ax), mx = fmax(y, ax);
-  const double t = mn * rcp_nr(mx + hyp);
-  const double z = t * t;
-  double p = pc.at[8];
+// theta = |atan2(y, x)| in [0, pi] for y >= 0, from y, nx = -x and rh = 1 / sqrt(x*x + y*y) (the caller has the
+// reciprocal norm already) — without a division and without a select:
+//   * octant fold: phi = atan2(min, max) in [0, pi/4] of (min, max) = sorted (y, |x|);
+//   * the point (max, min) is turned back by pi/8, so that sin(phi - pi/8) = (min cos(pi/8) - max sin(pi/8)) rh lies in
+//     +-sin(pi/8) and asin is a short odd polynomial there: phi = pi/8 + asin(n).  With p = y + |x| and d = y - |x|
+//     the sorted pair never has to be formed: min c - max s = p (c - s)/2 - |d| (c + s)/2;
+//   * unfold by sign transfers (v_bfi_b32 on the high dword) instead of compare + subtract + select: e = phi - pi/4 is
+//     <= 0, the octant fold maps it to -e exactly when y > |x| (sign of d); f = (that) - pi/4 is <= 0 again, the
+//     half-plane fold maps it to -f exactly when x < 0 (sign of nx); theta = f + pi/2.  (Rounding can leave e or f a few
+//     1e-17 on the wrong side of 0: the transfer then moves the angle by that much.)
+// 19 issue slots at degree 7, against 29 for the half-angle form t = min / (max + hyp) with its v_rcp_f64 (4 slots) +
+// Newton step and two compare/select folds.
+__device__ __forceinline__ double angle_abs(const poly_consts &pc, double y, double nx, double rh, double /*hyp*/) {
+  const double ax = fabs(nx);
+  const double d = y - ax, p = y + ax;
+  const double nu = fma(p, 2.70598050073098492e-01, -(fabs(d) * 6.53281482438188264e-01));  // (c -+ s)/2, c,s = cos,sin(pi/8)
+  const double n = nu * rh;
+  const double z = n * n;
+  double q = pc.as[SFW_ASIN_DEG];
 #pragma unroll
-  for (int n = 7; n >= 0; --n) p = fma(p, z, pc.at[n]);
-  double a = p * t;                                   // phi
-  a = (y > ax) ? (1.57079632679489661923 - a) : a;    // octant fold
-  a = (x < 0.0) ? (3.14159265358979323846 - a) : a;   // half-plane fold
-  return a;
+  for (int k = SFW_ASIN_DEG - 1; k >= 0; --k) q = fma(q, z, pc.as[k]);
+  const double e = fma(n, q, sgpr_const(-3.92699081698724155e-01));  // phi - pi/4 = asin(n) - pi/8 (scalar addend: no v_mov + v_fmac)
+  const double f = __builtin_copysign(e, d) - 7.85398163397448310e-01;  // (octant-folded angle) - pi/2
+  return __builtin_copysign(f, nx) + 1.57079632679489661923;
 }
 
 // ---- float ----------------------------------------------------------------
@@ -112,7 +154,8 @@ __device__ __forceinline__ float rcp_nr(float x) { return __builtin_amdgcn_rcpf(
 __device__ __forceinline__ float exp_fast(const poly_consts &, float x) {
   return __builtin_amdgcn_exp2f(fmaxf(x * 1.44269504088896340736f, -126.0f));
 }
-__device__ __forceinline__ float atan2_abs(const poly_consts &, float y, float x, float hyp) {
+__device__ __forceinline__ float angle_abs(const poly_consts &, float y, float nx, float /*rh*/, float hyp) {
+  const float x = -nx;
   const float ax = fabsf(x);
   const float mn = fminf(y, ax), mx = fmaxf(y, ax);
   const float t = mn * rcp_nr(mx + hyp);
