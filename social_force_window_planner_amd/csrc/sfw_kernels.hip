@@ -545,8 +545,8 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   // never changes a result)
   const R a = fmax(fma(dn * rl, k.neg_inv_gamma, k.ln_f_social), R(-800));
   const R t2 = l2 * (theta * theta);      // (B theta)^2 = gamma^2 |I|^2 theta^2; gamma^2 sits in c_vel / c_ang
-  const R ev = exp_fast(k.pc, fma(k.c_vel, t2, a));   // Fs exp(-|diff|/B - (n' B theta)^2)
-  R ea = exp_fast(k.pc, fma(k.c_ang, t2, a));         // Fs exp(-|diff|/B - (n  B theta)^2)
+  R ev, ea;  // Fs exp(-|diff|/B - (n' B theta)^2), Fs exp(-|diff|/B - (n B theta)^2)
+  exp_fast2(k.pc, fma(k.c_vel, t2, a), fma(k.c_ang, t2, a), ev, ea);
   // sign(theta) * exp(...): sign bit copied from cw, exact zero kept (relative rest)
   ea = (cw != 0.0) ? copysign_from(ea, cw) : R(0);
   const R gx = ix * rl, gy = iy * rl;    // Ihat
@@ -1084,22 +1084,24 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
 #pragma unroll
   for (int r = 0; r < NS; ++r) hi_[r] = 8 * (sl_[r] - i_[r] + A);
   const int wrap = 8 * A;
+  const char *rs_src = nullptr;
+  if (lane < 2 * Gn)
+    rs_src = reinterpret_cast<const char *>(L.rstep + static_cast<int64_t>(step_begin) * L.rstep_stride +
+                                            robot_sample_of_item(L, first_local + (lane >> 1))) + 16 * (lane & 1);
+  const int64_t rs_row_bytes = L.rstep_stride * static_cast<int64_t>(sizeof(sfw_robot_step));
 
   for (int step = step_begin; step < step_end; ++step) {
     // This step's robot records (32 B per sample, contiguous) go from the K1 table straight to
     // LDS (global_load_lds_dwordx4: no VGPRs), in flight during the pair pass.  The waves of a
     // launch start together and run the same instruction stream, so a load issued where it is
     // consumed stalls every resident wave of the SIMD at once (14 % of wave time in s_waitcnt
-    // at cfg2 before this, profiles/r01e).
-    for (int c = 0; c < 2 * Gn; c += WAVE)  // 16 B per lane, 64 lanes per instruction
-      if (c + lane < 2 * Gn) {
-        const int64_t rsample = robot_sample_of_item(L, first_local + ((c + lane) >> 1));
-        const char *src = reinterpret_cast<const char *>(L.rstep + static_cast<int64_t>(step) * L.rstep_stride + rsample) +
-                          16 * ((c + lane) & 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(s.rsb) + 16 * c),
-                                         16, 0, 0);
-      }
+    // at cfg2 before this, profiles/r01e).  Lane l < 2 Gn brings half (l & 1) of sample (l >> 1)'s record from
+    // its own pointer (G <= 32, plan_for), advanced by one table row per step (two VALU issues; forming the address from the item
+    // tables every step cost ~90 and, at 80 VGPRs, the scratch spills around it).
+    if (lane < 2 * Gn)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rs_src,
+                                       (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(s.rsb)), 16, 0, 0);
+    rs_src += rs_row_bytes;
     // ---- pair pass: social forces at the pre-step state -------------------
 #pragma unroll
     for (int r = 0; r < NS; ++r) jo_[r] = 8 * sl_[r];
@@ -1656,7 +1658,7 @@ static wave_plan plan_for(int A, int64_t T, int O, int form) {
   const int P = A * (A - 1) / 2;
   double best_score = P > 0 ? 0.82 * P / (64.0 * ((P + WAVE - 1) / WAVE)) : 0.0;
   if (A <= WAVE) {
-    const int g = WAVE / A < 64 ? WAVE / A : 64;
+    const int g = WAVE / A < 32 ? WAVE / A : 32;  // <= 32 samples per wave: two lanes per sample fetch its robot record
     const double sc = 1.0 * g * A / WAVE;
     if (sc >= best_score) { best_score = sc; best = wave_plan{g, 1, false}; }
   } else if (A <= 2 * WAVE) {
@@ -1666,7 +1668,7 @@ static wave_plan plan_for(int A, int64_t T, int O, int form) {
   // ... and a robot alone among laser points: the flat form spreads the points over eight lanes
   if (T <= 4096 && (A >= 2 || O > 0)) best = wave_plan{1, 0, true};
   if (form == SFW_K2_FLAT && (A >= 2 || O > 0)) best = wave_plan{1, 0, true};
-  if (form == SFW_K2_REGISTER && A <= 2 * WAVE) best = (A <= WAVE) ? wave_plan{WAVE / A, 1, false} : wave_plan{1, 2, false};
+  if (form == SFW_K2_REGISTER && A <= 2 * WAVE) best = (A <= WAVE) ? wave_plan{WAVE / A < 32 ? WAVE / A : 32, 1, false} : wave_plan{1, 2, false};
   return best;
 }
 

@@ -119,6 +119,23 @@ __device__ __forceinline__ double exp_fast(const poly_consts &pc, double x) {
   for (int n = SFW_EXP_DEG - 1; n >= 0; --n) p = fma(p, r, pc.ex[n]);
   return __builtin_amdgcn_ldexp(p, __double2loint(t));
 }
+// Two exponentials at once, their Horner chains interleaved: a lone wave per SIMD (shared-prefix levels, control-cycle
+// grids) pays the ~8-cycle dependent-issue latency of every link of a chain, two independent chains hide each other's.
+// Same operations on the same values as two exp_fast calls: bit-identical.
+__device__ __forceinline__ void exp_fast2(const poly_consts &pc, double x1, double x2, double &e1, double &e2) {
+  const double shift = 6755399441055744.0;  // 1.5 * 2^52
+  const double t1 = fma(x1, 1.4426950408889634074, shift), t2 = fma(x2, 1.4426950408889634074, shift);
+  const double k1 = t1 - shift, k2 = t2 - shift;
+  const double r1 = fma(k1, -6.93147180559945286227e-01, x1), r2 = fma(k2, -6.93147180559945286227e-01, x2);
+  double p1 = pc.ex[SFW_EXP_DEG], p2 = pc.ex[SFW_EXP_DEG];
+#pragma unroll
+  for (int n = SFW_EXP_DEG - 1; n >= 0; --n) {
+    p1 = fma(p1, r1, pc.ex[n]);
+    p2 = fma(p2, r2, pc.ex[n]);
+  }
+  e1 = __builtin_amdgcn_ldexp(p1, __double2loint(t1));
+  e2 = __builtin_amdgcn_ldexp(p2, __double2loint(t2));
+}
 // theta = |atan2(y, x)| in [0, pi] for y >= 0, from y, nx = -x and rh = 1 / sqrt(x*x + y*y) (the caller has the
 // reciprocal norm already) — without a division and without a select:
 //   * octant fold: phi = atan2(min, max) in [0, pi/4] of (min, max) = sorted (y, |x|);
@@ -153,6 +170,10 @@ __device__ __forceinline__ void rsqrt_sqrt(float x, float &rs, float &sq) {
 __device__ __forceinline__ float rcp_nr(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float exp_fast(const poly_consts &, float x) {
   return __builtin_amdgcn_exp2f(fmaxf(x * 1.44269504088896340736f, -126.0f));
+}
+__device__ __forceinline__ void exp_fast2(const poly_consts &pc, float x1, float x2, float &e1, float &e2) {
+  e1 = exp_fast(pc, x1);
+  e2 = exp_fast(pc, x2);
 }
 __device__ __forceinline__ float angle_abs(const poly_consts &, float y, float nx, float /*rh*/, float hyp) {
   const float x = -nx;
