@@ -112,7 +112,7 @@ struct sfw_planner_s {
   std::vector<char> h_agents;       // pos | vel | const | obstacles | grp | off | mem, 16-byte aligned parts
   size_t ao_vel = 0, ao_cst = 0, ao_obs = 0, ao_grp = 0, ao_off = 0, ao_mem = 0;
   int A = 0, O = 0, NG = 0, n_grp_mem = 0;
-  // ordered pairs (i, j) of agents with equal velocities at hand-over (e.g. standing people): see rest_forces
+  // ordered pairs (i, j) of agents with w x diff == 0 at hand-over (standing people, collinear walkers): see rest_forces
   std::vector<std::pair<int32_t, int32_t>> rest_pairs;
   const double *d_agent_rest = nullptr;  // A x (fx, fy) in `world`, or null when there is no such pair
   std::vector<std::pair<int32_t, int32_t>> st_rest_pairs;  // what the last stage evaluated them from: sfw_set_params
@@ -534,17 +534,19 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   return SFW_OK;
 }
 
-// Pairs at exact relative rest (w = v_i - v_j = 0: two standing people, a stopped robot next to a standing
-// person).  There the model's interaction angle theta is mathematically 0 and its angular term
-// -sign(theta) exp(-d/B - (n B theta)^2) leftNormal(Ihat) is discontinuous.  The kernels take sign(theta) from
-// w x diff, exactly 0 here, so their angular term vanishes.  lightsfm instead forms theta as the difference
-// of two atan2 of vectors equal up to rounding (angle(dhat) - angle(I/|I|), I = lambda*0 + dhat), so its
-// sign(theta) is -1, 0 or +1 by the rounding of the HOST's libm — a full-magnitude lateral force on an
-// ordinary scene.  Velocities can only coincide in the state the caller hands over (from step 1 on every
-// agent has been pushed by a different force), and that state is the same for every sample, so this term
-// is evaluated here, once per stage, with the same expression sequence and the same libm the reference would
-// run on this host (computeSocialForce), and added to the agents' starting forces.
-// out: A x (fx, fy).
+// Pairs with w x diff == 0 exactly, w = v_i - v_j: relative rest (two standing people, a stopped robot next to a
+// standing person) and motion exactly along the connecting line (two people on one grid-aligned line walking towards
+// or away from each other).  There the model's interaction angle theta is mathematically 0 or +-pi and its angular
+// term -sign(theta) exp(-d/B - (n B theta)^2) leftNormal(Ihat) is discontinuous.  The kernels take sign(theta) from
+// w x diff, exactly 0 here, so their angular term vanishes.  lightsfm instead forms theta as the difference of two
+// atan2 — of vectors equal up to rounding when I = lambda w + dhat points along dhat (sign(theta) = -1, 0 or +1 by the
+// rounding of the HOST's libm: a full-magnitude lateral force on an ordinary scene), of opposite vectors when the pair
+// separates faster than 1/lambda (theta = +-pi by the sign of a zero).  Such a configuration can only come from the state
+// the caller hands over (from step 1 on every agent has been pushed by a different force — the reference's own lateral
+// term breaks the alignment), and that state is the same for every sample, so this term is evaluated here, once per
+// stage, with the same expression sequence and the same libm the reference would run on this host (SURVEY.md Appendix
+// A: computeSocialForce), and added to the agents' starting forces.  Bug-compatibility with the restated text of an
+// unpinned dependency, not a CPU path: no sample is scored on the host.  out: A x (fx, fy).
 void rest_forces(const sfw_params &p, const std::vector<std::pair<int32_t, int32_t>> &pairs, const double *pos, const double *vel,
                  int A, double *out) {
   for (int i = 0; i < 2 * A; ++i) out[i] = 0.0;
@@ -1051,36 +1053,21 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   h->n_grp_mem = n_mem;
   h->A = A;
   h->O = O;
-  // pairs with equal velocities (v_i - v_j == 0 in both components; -0.0 equals +0.0): agents ordered by velocity, the
-  // pairs inside each run of equal velocities — O(A log A) on the control-cycle path instead of all A^2 / 2 compares
+  // Pairs whose w x diff is exactly 0 in the handed-over state — relative rest (w = 0) and motion exactly along the
+  // connecting line — are the pairs for which the kernels' sign(theta) = sign(w x diff) is 0 while lightsfm's theta is
+  // rounding noise around 0 or exactly +-pi: their angular terms are evaluated on the host (rest_forces).  The test is
+  // the kernels' own expression (pair_force_state), IEEE fma on both sides.  All pairs: ~1 ns each, 1275 at 50
+  // pedestrians; the scoring that follows costs A^2 per sample-step.
   h->rest_pairs.clear();
-  std::vector<int32_t> order(static_cast<size_t>(A));
-  for (int i = 0; i < A; ++i) order[static_cast<size_t>(i)] = i;
-  auto vkey = [&](int32_t i) { return std::make_pair(agents[i].vx + 0.0, agents[i].vy + 0.0); };  // x + 0.0: -0.0 -> +0.0
-  std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-    const auto ka = vkey(a), kb = vkey(b);
-    return ka != kb ? ka < kb : a < b;
-  });
-  for (size_t b = 0; b < order.size();) {
-    size_t e = b + 1;
-    while (e < order.size() && vkey(order[e]) == vkey(order[b])) ++e;
-    for (size_t x = b; x < e; ++x)
-      for (size_t y = x + 1; y < e; ++y) {
-        const int32_t i = order[x], j = order[y];  // i < j: runs are in index order
-        if (!(agents[i].x == agents[j].x && agents[i].y == agents[j].y)) {
-          h->rest_pairs.emplace_back(i, j);
-          h->rest_pairs.emplace_back(j, i);
-        }
+  for (int i = 0; i < A; ++i)
+    for (int j = i + 1; j < A; ++j) {
+      const double dx = agents[j].x - agents[i].x, dy = agents[j].y - agents[i].y;
+      const double wx = agents[i].vx - agents[j].vx, wy = agents[i].vy - agents[j].vy;
+      if (std::fma(wx, dy, -(wy * dx)) == 0.0 && !(dx == 0.0 && dy == 0.0)) {
+        h->rest_pairs.emplace_back(i, j);
+        h->rest_pairs.emplace_back(j, i);
       }
-    b = e;
-  }
-  // rest_forces adds a pair's term to its first agent in list order: keep the order of the all-pairs scan (i ascending,
-  // then j), so that an agent's sum is rounded as before
-  std::sort(h->rest_pairs.begin(), h->rest_pairs.end(), [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) {
-    const auto ka = std::make_pair(std::min(a.first, a.second), std::max(a.first, a.second));
-    const auto kb = std::make_pair(std::min(b.first, b.second), std::max(b.first, b.second));
-    return ka != kb ? ka < kb : a.first < b.first;
-  });
+    }
   return SFW_OK;
 }
 
