@@ -3,7 +3,10 @@
 // whole-cycle medians of  set_costmap + set_footprint + set_agents + score_grid (blocking).
 //
 //   build: make -C social_force_window_planner_amd/csrc latency
-//   run:   build/cycle_latency [cycles] [laser points]
+//   run:   build/cycle_latency [cycles] [laser points] [markers]
+// markers = 1: every cycle also fetches all 45 Trajectories (what the reference's MarkerArray holds, :347-386) with
+// sfw_set_points_capture on (the scoring launch leaves the points: one extra D2H); markers = 2: the same without the
+// capture (the dump re-runs the rollout).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -25,6 +28,7 @@ static double median(std::vector<double> v) {
 int main(int argc, char **argv) {
   const int cycles = argc > 1 ? std::atoi(argv[1]) : 200;
   const int n_laser = argc > 2 ? std::atoi(argv[2]) : 0;  // obstacles1: laser points near the robot
+  const int markers = argc > 3 ? std::atoi(argv[3]) : 0;
   std::vector<double> laser;
   for (int i = 0; i < n_laser; ++i) {  // a wall 1.5 m to the left and a pillar ahead
     const double u = (i + 0.5) / n_laser;
@@ -70,7 +74,11 @@ int main(int argc, char **argv) {
       }
       std::vector<double> costs(45);
       sfw_best best;
-      std::vector<double> t_map, t_fp, t_ag, t_score, t_all;
+      std::vector<double> t_map, t_fp, t_ag, t_score, t_all, t_mark;
+      const int S = static_cast<int>(p.sim_time / p.sim_granularity + 0.5);
+      std::vector<double> pts(static_cast<size_t>(45) * S * 3);
+      std::vector<int32_t> npts(45);
+      if (markers == 1) sfw_set_points_capture(h, 1);
       for (int c = 0; c < cycles + 10; ++c) {
         const auto t0 = clk::now();
         int rc = sfw_set_costmap(h, cells.data(), N, N, origin, origin, res);
@@ -81,17 +89,21 @@ int main(int argc, char **argv) {
         const double d = us_since(t0);
         rc |= sfw_score_grid(h, &rs, lin, 5, ang, 9, &ga, costs.data(), &best);
         const double e = us_since(t0);
+        if (markers) rc |= sfw_grid_points_batch(h, 0, 45, pts.data(), npts.data());
+        const double f = us_since(t0);
         if (rc != SFW_OK) {
           std::fprintf(stderr, "error: %s\n", sfw_last_error(h));
           return 1;
         }
         if (c >= 10) {
-          t_map.push_back(a); t_fp.push_back(b - a); t_ag.push_back(d - b); t_score.push_back(e - d); t_all.push_back(e);
+          t_map.push_back(a); t_fp.push_back(b - a); t_ag.push_back(d - b); t_score.push_back(e - d); t_all.push_back(f);
+          t_mark.push_back(f - e);
         }
       }
-      std::printf("N=%2d O=%3d S=%2d: cycle %6.1f us  (set_costmap %5.1f  set_footprint %4.1f  set_agents %5.1f  score_grid %6.1f)  best index %lld\n",
-                  n_people, n_laser, static_cast<int>(p.sim_time / p.sim_granularity + 0.5), median(t_all), median(t_map),
-                  median(t_fp), median(t_ag), median(t_score), static_cast<long long>(best.index));
+      std::printf("N=%2d O=%3d S=%2d: cycle %6.1f us  (set_costmap %5.1f  set_footprint %4.1f  set_agents %5.1f  score_grid %6.1f",
+                  n_people, n_laser, S, median(t_all), median(t_map), median(t_fp), median(t_ag), median(t_score));
+      if (markers) std::printf("  points of 45 samples %5.1f [%s]", median(t_mark), markers == 1 ? "captured" : "re-run");
+      std::printf(")  best index %lld\n", static_cast<long long>(best.index));
       sfw_destroy(h);
     }
   return 0;

@@ -306,6 +306,13 @@ int sfw_grid_points(sfw_handle h, int64_t index, double *points_xyth,
  * reports i + 1 poses, as the reference does (it returns at the contact, :613-627): when the range holds
  * costmap-rejected samples their pedestrians are integrated in an extra pass of this call. */
 int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *points_xyth, int32_t *n_points);
+/* Marker support without a second rollout: with capture on, a scoring launch over a grid small enough for the
+ * one-launch rollout (at most 2048 samples and 512 steps: a control cycle's 5 x 9 samples) also leaves every
+ * sample's Trajectory points, point count and contact step on the device, and sfw_grid_points(_batch) of that
+ * launch is ONE device-to-host copy instead of re-running the rollout (and, when a sample was rejected on the
+ * costmap, the pedestrian integration).  Costs and selection are unaffected.  Larger grids ignore it.  Off by
+ * default; takes effect at the next sfw_grid_launch / sfw_score_grid. */
+int sfw_set_points_capture(sfw_handle h, int32_t enabled);
 /* Raw HIP stream (hipStream_t) the handle launches on, for callers that want
  * to record their own events. */
 void *sfw_stream(sfw_handle h);

@@ -167,6 +167,7 @@ EXPORTED_SYMBOLS = (
     "sfw_last_clock_ghz",
     "sfw_grid_points",
     "sfw_grid_points_batch",
+    "sfw_set_points_capture",
     "sfw_stream",
     "sfw_multi_create",
     "sfw_multi_destroy",

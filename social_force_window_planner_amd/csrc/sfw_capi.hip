@@ -139,6 +139,11 @@ struct sfw_planner_s {
   bool staged = false, launched = false, launched_timed = false;
   bool timing = false;  // sfw_set_timing: record the per-kernel events sfw_last_launch_ms reads
   int k2_form = SFW_K2_AUTO;     // sfw_set_k2_form / SFW_FORCE_FLAT
+  // sfw_set_points_capture: a grid small enough for the fused K1 (a control cycle's samples) leaves its Trajectory points,
+  // point counts and contact steps during the scoring launch itself, in one buffer -> the dump is one D2H copy
+  bool capture_points = false, captured = false;
+  dev_buf<char> cap;             // points (24 S T bytes) | n_points (4 T) | contact steps (4 T)
+  pinned_buf pin_cap;
 
   // shared-prefix plan of the staged grid (sfw_device.h: sfw_cls_agent); no levels: not used
   struct level_tables {               // offsets (ints) into d_cls
@@ -723,11 +728,34 @@ int launch_common(sfw_handle h) {
       h->chunk_ev.push_back(e);
     }
   }
+  // Trajectory points on request (sfw_set_points_capture), when the whole grid goes through the fused K1
+  h->captured = false;
+  char *cap_pts = nullptr, *cap_n = nullptr, *cap_coll = nullptr;
+  if (h->capture_points && single) {
+    sfw_launch probe;
+    fill_launch(h, probe, 0, T, chunk);
+    if (sfw_rollout_is_fused(probe)) {
+      const size_t pts_bytes = sizeof(double) * 3 * static_cast<size_t>(S) * static_cast<size_t>(T);
+      SFW_HIP(h, h->cap.reserve(pts_bytes + 8 * static_cast<size_t>(T)));
+      cap_pts = h->cap.p;
+      cap_n = cap_pts + pts_bytes;
+      cap_coll = cap_n + 4 * static_cast<size_t>(T);
+      h->captured = true;
+    }
+  }
   int c = 0;
   for (int64_t b = 0; b < T; b += chunk, ++c) {
     const int64_t n = (T - b < chunk) ? (T - b) : chunk;
     sfw_launch L;
     fill_launch(h, L, b, n, chunk);
+    if (h->captured) {
+      L.points = reinterpret_cast<double *>(cap_pts);
+      L.n_points = reinterpret_cast<int32_t *>(cap_n);
+      L.coll_step = reinterpret_cast<int32_t *>(cap_coll);
+      // a sample the costmap rejects at pose a may touch a pedestrian at an earlier step b < a, where the reference's
+      // Trajectory ends (ref :613-627): integrated all the same, its cost stays -1 (finish_wave)
+      L.force_alive = 1;
+    }
     L.clock_probe = timing ? h->clock.p : nullptr;  // every K2 dispatch writes it; the last one (the launch over the samples) stays
     if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c], h->stream));
     if (prefix) {
@@ -909,6 +937,8 @@ int sfw_destroy(sfw_handle h) {
   h->fcode.release();
   h->partials.release();
   h->clock.release();
+  h->cap.release();
+  h->pin_cap.release();
   h->points.release();
   h->n_points.release();
   h->one_out.release();
@@ -1239,6 +1269,12 @@ int sfw_last_launch_ms(sfw_handle h, int32_t which, float *ms_out) {
   return SFW_OK;
 }
 
+int sfw_set_points_capture(sfw_handle h, int32_t enabled) {
+  if (!h) return SFW_ERR_INVALID_ARG;
+  h->capture_points = enabled != 0;
+  return SFW_OK;
+}
+
 int sfw_last_clock_ghz(sfw_handle h, double *ghz_out) {
   if (!h || !ghz_out) return SFW_ERR_INVALID_ARG;
   if (!h->launched) return fail(h, SFW_ERR_STATE, "last_clock_ghz before grid_launch");
@@ -1264,6 +1300,22 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
   SFW_HIP(h, hipSetDevice(h->device));
   const int S = num_steps_of(h->params);
   const size_t n = static_cast<size_t>(count);
+  if (h->launched && h->captured) {
+    // the scoring launch left everything (sfw_set_points_capture): ONE copy of points | counts | contact steps, no kernel
+    const size_t pts_bytes = sizeof(double) * 3 * static_cast<size_t>(S) * static_cast<size_t>(T), total = pts_bytes + 8 * static_cast<size_t>(T);
+    SFW_HIP(h, h->pin_cap.reserve(total));
+    SFW_HIP(h, hipMemcpyAsync(h->pin_cap.p, h->cap.p, total, hipMemcpyDeviceToHost, h->stream));
+    SFW_HIP(h, hipStreamSynchronize(h->stream));
+    const int32_t *np = reinterpret_cast<const int32_t *>(h->pin_cap.p + pts_bytes), *coll = np + T;
+    std::memcpy(points_xyth, h->pin_cap.p + sizeof(double) * 3 * static_cast<size_t>(S) * static_cast<size_t>(first), sizeof(double) * 3 * S * n);
+    for (size_t i = 0; i < n; ++i) {
+      const int32_t c = coll[first + static_cast<int64_t>(i)];
+      int32_t k = np[first + static_cast<int64_t>(i)];
+      if (c >= 0 && c + 1 < k) k = c + 1;  // rejected by contact at step c: poses 0..c were added (ref :578, :613-627)
+      n_points[i] = k;
+    }
+    return SFW_OK;
+  }
   SFW_HIP(h, h->points.reserve(3 * static_cast<size_t>(S) * n));
   SFW_HIP(h, h->n_points.reserve(n));
   // Re-run K1 for those samples into scratch outputs so the grid results stay intact.  The scratch is

@@ -158,6 +158,8 @@ hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream);  // = po
 hipError_t sfw_launch_rollout_poses(const sfw_launch &L, hipStream_t stream);
 hipError_t sfw_launch_rollout_costmap(const sfw_launch &L, hipStream_t stream);
 hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream);
+// true when sfw_launch_rollout_poses runs all of K1 in one launch (small grids): the only form that writes L.points
+bool sfw_rollout_is_fused(const sfw_launch &L);
 // Reduces costs[0..T) to one sfw_sel at *out (device memory).  partials must
 // hold >= sfw_argmin_partials(T) records.
 int64_t sfw_argmin_partials(int64_t T);

@@ -54,8 +54,10 @@ def lib():
         L.sfwh_trajectory_points.argtypes = [vp, C.c_int64, vp, C.c_int32]
         L.sfwh_all_trajectories.argtypes = [vp, vp, C.c_int32, vp]
         L.sfwh_all_trajectories.restype = C.c_int64
-        L.sfwh_markers.argtypes = [vp, vp, vp, vp]
+        L.sfwh_markers.argtypes = [vp, vp, vp, vp, C.c_int64]
         L.sfwh_markers.restype = C.c_int64
+        L.sfwh_set_marker_capture.argtypes = [vp, C.c_int32]
+        L.sfwh_set_marker_capture.restype = None
         L.sfwh_get_yaw.argtypes = [C.c_double] * 4
         L.sfwh_get_yaw.restype = C.c_double
         _lib = L
@@ -114,8 +116,14 @@ class HostPlanner:
         rgba = np.zeros((n_samples, 4), dtype=np.float32)
         counts = np.zeros(n_samples, dtype=np.int32)
         z0 = np.zeros(n_samples, dtype=np.float64)
-        n = lib().sfwh_markers(self._h, rgba.ctypes.data, counts.ctypes.data, z0.ctypes.data)
+        n = lib().sfwh_markers(self._h, rgba.ctypes.data, counts.ctypes.data, z0.ctypes.data, n_samples)
+        if n > n_samples:
+            raise ValueError(f"markers({n_samples}): the planner holds {n} samples")
         return None if n < 0 else (rgba, counts, z0)
+
+    def set_marker_capture(self, on=True):
+        """SFWPlanner::setMarkerCapture: the scoring launch also leaves the Trajectory points (one copy per marker dump)."""
+        lib().sfwh_set_marker_capture(self._h, 1 if on else 0)
 
     def set_devices(self, devices, host_reduce=False):
         """SFWPlanner::setDevices: grid rows over several devices from this process (before the first scoring call)."""

@@ -238,10 +238,14 @@ geometry_msgs::msg::TwistStamped SFWPlannerNode::computeVelocityCommands(const g
   Twist in_speed;
   in_speed.linear = Vector3{speed.linear.x, speed.linear.y, 0.0};
   in_speed.angular.z = speed.angular.z;
+  // The reference fills and publishes its MarkerArray every cycle (:283, :301-309).  Here the points cost a device-to-host
+  // copy (and, on grids too large for the capture, a second rollout): only while somebody listens to the topic.
+  const bool want_markers = traj_pub_->get_subscription_count() > 0;
+  sfw_planner_->setMarkerCapture(want_markers);
   const bool ok = sfw_planner_->findBestAction(toPod(robot_pose), in_speed, cmd);  // ref :281
-  // ref :283, :301-309: the trajectory markers go out on both exits (red rejected, blue valid, green selected)
+  // the trajectory markers go out on both exits (red rejected, blue valid, green selected)
   std::vector<SFWPlanner::MarkerData> md;
-  if (sfw_planner_->getMarkers(md)) {
+  if (want_markers && sfw_planner_->getMarkers(md)) {
     visualization_msgs::msg::MarkerArray markers;
     const auto stamp = node_->get_clock()->now();
     for (const SFWPlanner::MarkerData &d : md) {

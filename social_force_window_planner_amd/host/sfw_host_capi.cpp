@@ -201,12 +201,13 @@ int64_t sfwh_all_trajectories(void *hv, double *xyth, int32_t cap, int32_t *coun
   }
   return static_cast<int64_t>(ts.size());
 }
-// markers of the last cycle: rgba = T x 4 floats, counts = T point counts, z0 = T z of each marker's first point (0 if none);
-// returns T, or -1 when the cycle left the markers untouched
-int64_t sfwh_markers(void *hv, float *rgba, int32_t *counts, double *z0) {
+// markers of the last cycle: rgba = cap x 4 floats, counts = cap point counts, z0 = cap z of each marker's first point (0 if
+// none); returns T, or -1 when the cycle left the markers untouched.  Nothing is written when cap < T.
+int64_t sfwh_markers(void *hv, float *rgba, int32_t *counts, double *z0, int64_t cap) {
   HostHandle *h = static_cast<HostHandle *>(hv);
   std::vector<SFWPlanner::MarkerData> ms;
   if (!h->planner->getMarkers(ms)) return -1;
+  if (static_cast<int64_t>(ms.size()) > cap) return static_cast<int64_t>(ms.size());
   for (size_t i = 0; i < ms.size(); ++i) {
     rgba[4 * i] = ms[i].r; rgba[4 * i + 1] = ms[i].g; rgba[4 * i + 2] = ms[i].b; rgba[4 * i + 3] = ms[i].a;
     counts[i] = static_cast<int32_t>(ms[i].points.size());
@@ -214,6 +215,7 @@ int64_t sfwh_markers(void *hv, float *rgba, int32_t *counts, double *z0) {
   }
   return static_cast<int64_t>(ms.size());
 }
+void sfwh_set_marker_capture(void *hv, int32_t on) { static_cast<HostHandle *>(hv)->planner->setMarkerCapture(on != 0); }
 double sfwh_get_yaw(double x, double y, double z, double w) { return getYaw(Quaternion{x, y, z, w}); }
 }
 

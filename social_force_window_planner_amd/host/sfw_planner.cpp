@@ -106,6 +106,7 @@ void SFWPlanner::ensureDevice() {
       raise("sfw_multi_create (devices not visible, listed twice without host_reduce, or librccl.so missing)", rc);
     }
     handle_ = sfw_multi_rank_handle(multi_, 0);
+    setMarkerCapture(marker_capture_);
     return;
   }
   const int rc = sfw_create(&abi, device_, &handle_);
@@ -113,6 +114,7 @@ void SFWPlanner::ensureDevice() {
     handle_ = nullptr;
     raise("sfw_create (no HIP device? this planner has no CPU scoring path)", rc);
   }
+  setMarkerCapture(marker_capture_);
 }
 
 void SFWPlanner::setDevices(std::vector<int> devices, bool host_reduce) {
@@ -136,6 +138,14 @@ void SFWPlanner::raise(const char *what, int status) const {
 void SFWPlanner::setParams(const ControllerParams &p) {
   std::lock_guard<std::mutex> l(configuration_mutex_);
   params_ = p;
+}
+void SFWPlanner::setMarkerCapture(bool on) {
+  marker_capture_ = on;
+  if (multi_) {
+    for (int32_t r = 0; r < sfw_multi_ranks(multi_); ++r) sfw_set_points_capture(sfw_multi_rank_handle(multi_, r), on ? 1 : 0);
+  } else if (handle_) {
+    sfw_set_points_capture(handle_, on ? 1 : 0);
+  }
 }
 void SFWPlanner::setFootprint(std::vector<Point> footprint) { footprint_spec_ = std::move(footprint); }
 void SFWPlanner::setSampleSets(std::vector<double> lin, std::vector<double> ang) {
@@ -369,6 +379,7 @@ bool SFWPlanner::getTrajectories(std::vector<Trajectory> &out) {
 
 bool SFWPlanner::getMarkers(std::vector<MarkerData> &out) {
   const size_t T = linvels_.size() * angvels_.size();
+  if (T == 0) return false;  // empty sample sets: no markers to touch
   auto fill = [](MarkerData &m, const Trajectory &t, double z) {
     for (unsigned k = 0; k < t.getPointsSize(); ++k) {
       double x, y, th;

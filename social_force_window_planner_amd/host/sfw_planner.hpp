@@ -161,6 +161,10 @@ class SFWPlanner {
     std::vector<Point> points;
   };
   bool getMarkers(std::vector<MarkerData> &out);
+  // Whether the cycle's scoring launch should also leave the Trajectory points (sfw_set_points_capture): on while
+  // somebody listens to the markers — getMarkers is then one device-to-host copy per cycle —, off otherwise (the
+  // reference fills its MarkerArray every cycle, :347-386; nothing needs the points when nobody subscribes).
+  void setMarkerCapture(bool on);
   int wpIndex() const { return wp_index_; }
   bool running() const { return running_; }
 
@@ -186,6 +190,7 @@ class SFWPlanner {
   sfw_best last_best_{};
   int last_branch_ = kNotRunning;
   bool grid_staged_ = false;
+  bool marker_capture_ = false;
 
   int wp_index_ = -1;
   bool running_ = false, new_plan_ = false, goal_reached_ = false;

@@ -90,6 +90,7 @@ def lib():
         L.sfw_last_clock_ghz.argtypes = [vp, C.POINTER(C.c_double)]
         L.sfw_grid_points.argtypes = [vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32)]
         L.sfw_grid_points_batch.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
+        L.sfw_set_points_capture.argtypes = [vp, C.c_int32]
         L.sfw_stream.argtypes = [vp]
         L.sfw_stream.restype = vp
         L.sfw_multi_create.argtypes = [C.POINTER(SfwParams), C.POINTER(C.c_int), C.c_int32, C.c_int32, C.POINTER(vp)]
@@ -247,6 +248,10 @@ class HipScorer:
         v = C.c_double()
         self._check(lib().sfw_last_clock_ghz(self._h, C.byref(v)), "sfw_last_clock_ghz")
         return v.value
+
+    def set_points_capture(self, enabled=True):
+        """Small grids: the scoring launch also leaves the Trajectory points (one D2H per dump, no second rollout)."""
+        self._check(lib().sfw_set_points_capture(self._h, 1 if enabled else 0), "sfw_set_points_capture")
 
     def grid_points_batch(self, first, count, n_steps):
         """Trajectory points of `count` consecutive samples: (points[count, n_steps, 3], n_points[count])."""

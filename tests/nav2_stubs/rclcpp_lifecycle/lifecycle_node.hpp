@@ -5,6 +5,7 @@ namespace rclcpp_lifecycle {
 template <class M> class LifecyclePublisher {
  public:
   void publish(const M &) {}
+  size_t get_subscription_count() const { return 0; }  // rclcpp::PublisherBase
   void on_activate() {}
   void on_deactivate() {}
 };

@@ -243,3 +243,40 @@ def test_marker_data_of_every_branch(oracle_mod, host_built):
     assert r2[2] == BRANCH_APPROACH
     rgba, counts, z0 = h2.markers(45)
     assert np.allclose(rgba[0], [0, 1, 0, 1]) and counts[0] == 40 and (counts[1:] == 0).all() and z0[0] == 0.0
+
+
+@pytest.mark.gpu
+def test_marker_capture_gives_the_same_markers_without_a_second_rollout(host_built):
+    """SFWPlanner::setMarkerCapture (sfw_set_points_capture): the scoring launch of a control-cycle grid leaves the
+    Trajectory points itself; markers, trajectories, commands and costs are those of the planner that re-runs the
+    rollout for the dump — incl. samples rejected on the costmap and people close enough for contacts."""
+    scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["ref5x9"], n_people=4, seed=92))
+    cells = scene.cells.copy()
+    cells[:] = 0
+    cells[:, 118:121] = 254
+    scene.cells[:] = cells
+    ag = scene.agents
+    ag[1].x, ag[1].y, ag[1].vx, ag[1].vy = 0.8, 0.1, -0.4, 0.0   # walks into the robot: contacts before the wall
+    ag[1].goal_x, ag[1].goal_y = -0.2, 0.1
+    plain = host_built.HostPlanner(default_ctrl_params(), scene)
+    cap = host_built.HostPlanner(default_ctrl_params(), scene)
+    cap.set_marker_capture(True)           # before the device handle exists: applied when it is created
+    plan = [[x, 0.1 * x, 0.0] for x in np.linspace(0.0, 4.0, 17)]
+    for pl in (plain, cap):
+        pl.update_plan(plan)
+    pose, vel = [0, 0, 0], [0.3, 0, 0]
+    for cycle in range(3):
+        rp, rc = plain.find_best_action(pose, vel), cap.find_best_action(pose, vel)
+        assert rp[0] == rc[0] and rp[2] == rc[2] and np.array_equal(rp[1], rc[1])
+        assert np.array_equal(plain.last_costs(), cap.last_costs())
+        mp, mc = plain.markers(45), cap.markers(45)
+        for a, b in zip(mp, mc):
+            assert np.array_equal(a, b)
+        tp, np_ = plain.all_trajectories(45, 40)
+        tc, nc = cap.all_trajectories(45, 40)
+        assert np.array_equal(np_, nc) and np.array_equal(tp, tc)
+        assert (np_ < 40).any() and len(set(np_.tolist())) > 3   # costmap rejections and contacts at several steps
+        if cycle == 1:
+            cap.set_marker_capture(False)  # switching it off mid-run falls back to the second rollout
+    with pytest.raises(ValueError):
+        cap.markers(10)                    # too small a buffer is refused, not overrun (ADVICE r2)

@@ -362,6 +362,17 @@ def test_points_of_a_sample_rejected_by_contact_before_its_illegal_pose(oracle_m
             cg, pg = g.score_one(scene.robot_state, vx, 0.0, vth, scene.goal_args)
             assert cg == -1.0 and pg.shape == po.shape and np.allclose(pg, po, atol=1e-13)
     assert n_double >= 3, f"scene does not exercise the corner (only {n_double} doubly rejected samples)"
+    # sfw_set_points_capture: the scoring launch leaves the same points, counts and contact steps itself (one D2H)
+    gcap = hip_mod.HipScorer(p)
+    gcap.set_points_capture(True)
+    gcap.load_scene(scene)
+    cc, cb = gcap.score_grid(scene.robot_state, lin, ang, scene.goal_args)
+    pts_c, cnt_c = gcap.grid_points_batch(0, len(lin) * len(ang), S)
+    assert np.array_equal(cc, gc) and cb == gb and np.array_equal(cnt_c, cnt)
+    for i in range(len(cnt)):
+        assert np.array_equal(pts_c[i, :cnt[i]], pts[i, :cnt[i]])
+    sub_p, sub_n = gcap.grid_points_batch(7, 5, S)
+    assert np.array_equal(sub_n, cnt[7:12]) and np.array_equal(sub_p[0, :cnt[7]], pts[7, :cnt[7]])
     # the grid results are untouched by the dump
     gc2, gb2, _ = None, None, None
     g.stage(scene.robot_state, lin, ang, scene.goal_args)
