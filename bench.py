@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each secondary workload")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (gloo: CPU tensors; lets several ranks share one GPU in tests)")
+    ap.add_argument("--inproc-workload", default="cfg5",
+                    help="N > 1: the workload rank 0 also scores through sfw_multi_score_grid over all N devices (extra.inproc_multi_*)")
     ap.add_argument("--grid", default=None, help="override the sample grid, e.g. 512x512 (experiments only)")
     ap.add_argument("--verify", action="store_true", help="check the GPU result against the oracle on a sample subset")
     ap.add_argument("--resident", action="store_true",
@@ -249,6 +251,7 @@ def run_config(workload_name, precision, steps, warmup, ctx, scaling="weak", res
         "global_key": win_key,
         "winner_rank": win_rank,
         "per_rank": per_rank,
+        "clock_ghz": job.scorer.sustained_clock_ghz(),
     }
 
 
@@ -293,7 +296,7 @@ def inproc_multi(workload_name, precision, devices, exchange, steps, warmup):
 
 def measured_traffic(workload_name):
     """HBM bytes per launch from the committed PMC passes (profiles/r0N_traffic.json, newest first), or None."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f).get(workload_name)
@@ -387,6 +390,7 @@ def extra_entry(name, precision, steps, warmup, ctx):
         "roofline_frac": rf["frac"],
         "roofline_executed_frac": rf["executed_frac"],
         "chunks": j.plan["chunks"],
+        "sustained_clock_ghz": r["clock_ghz"],
         "cmd_vel_index": r["best"]["index"],
         "n_valid": r["best"]["n_valid"],
     }
@@ -458,6 +462,9 @@ def main():
         "cmd_vel": {"vx": res["best"]["vx"], "vtheta": res["best"]["vtheta"], "cost": res["best"]["cost"],
                     "index": res["best"]["index"], "n_valid": res["best"]["n_valid"]},
         "roofline": roofline_for(job, res["k2_ms"], args.precision),
+        # shader clock the last social-force launch really ran at (wave 0's s_memtime / s_memrealtime): boxes and thermal
+        # states differ by ~10 %, kernel times of different runs are only comparable next to it
+        "sustained_clock_ghz": res["clock_ghz"],
     }
     if world > 1:
         from social_force_window_planner_amd import multi_gpu
@@ -493,12 +500,16 @@ def main():
         # The plugin-shaped path at N > 1: rank 0 ALONE drives all N devices from one process through
         # sfw_multi_score_grid over SFW_MULTI_RCCL (ncclCommInitAll + one grouped ncclAllReduce(min) per call); the other
         # ranks wait at the barrier below.  Same cfg5 grid as extra.cfg5_strong, so the two paths' numbers sit side by side.
+        # (--backend gloo = ranks sharing GPUs in tests: host-reduce ranks on this rank's device instead.)
         if rank == 0:
-            try:
-                extra["inproc_multi_cfg5"] = inproc_multi("cfg5", args.precision, list(range(world)), 0, 3, 1)
-                extra["inproc_multi_target"] = inproc_multi(args.workload, args.precision, list(range(world)), 0, 20, 3)
-            except Exception as e:  # a broken RCCL install must not take the headline line down
-                extra["inproc_multi_cfg5"] = {"error": repr(e)}
+            from social_force_window_planner_amd._abi import SFW_MULTI_HOST_REDUCE, SFW_MULTI_RCCL
+
+            devs, xchg = (list(range(world)), SFW_MULTI_RCCL) if args.backend == "nccl" else ([local_rank] * world, SFW_MULTI_HOST_REDUCE)
+            for name, st, wu in ((args.inproc_workload, 3, 1), (args.workload, 20, 3)):
+                try:
+                    extra["inproc_multi_" + name] = inproc_multi(name, args.precision, devs, xchg, st, wu)
+                except Exception as e:  # a broken RCCL install must not take the headline line down
+                    extra["inproc_multi_" + name] = {"error": repr(e)}
         dist.barrier()
     if rank == 0 and world == 1 and not args.resident:
         job = GridJob(args.workload, args.precision, 0, 1, local_rank)

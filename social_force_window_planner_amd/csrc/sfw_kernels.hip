@@ -954,6 +954,28 @@ template <typename T> __device__ __forceinline__ T &lds_at(char *, unsigned byte
   return *(T *)reinterpret_cast<__attribute__((address_space(3))) T *>(static_cast<uintptr_t>(byte_off));
 }
 
+// State (px, py, vx, vy) of the two agents of a pair from the LDS planes: EIGHT ds_read_b64 with immediate plane offsets
+// and one wait.  Left to the compiler the loads are merged into four ds_read2st64_b64, which the LDS serves at half the
+// rate (8 cycles per wave-instruction for 16 bytes per lane against 2 x 2 for two ds_read_b64, MI355X_MICROARCH.md
+// §LDS) — on the LDS pipe that the flat form keeps 84 % busy.  PY/VX/VY: byte distances of the planes (compile-time).
+template <int PY, int VX, int VY>
+__device__ __forceinline__ void lds_pair_state(uint32_t io, uint32_t jo, double &pix, double &piy, double &vix, double &viy,
+                                               double &pjx, double &pjy, double &vjx, double &vjy) {
+  asm volatile(
+      "ds_read_b64 %0, %8\n\t"
+      "ds_read_b64 %4, %9\n\t"
+      "ds_read_b64 %1, %8 offset:%10\n\t"
+      "ds_read_b64 %5, %9 offset:%10\n\t"
+      "ds_read_b64 %2, %8 offset:%11\n\t"
+      "ds_read_b64 %6, %9 offset:%11\n\t"
+      "ds_read_b64 %3, %8 offset:%12\n\t"
+      "ds_read_b64 %7, %9 offset:%12\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(pix), "=&v"(piy), "=&v"(vix), "=&v"(viy), "=&v"(pjx), "=&v"(pjy), "=&v"(vjx), "=&v"(vjy)
+      : "v"(io), "v"(jo), "n"(PY), "n"(VX), "n"(VY)
+      : "memory");
+}
+
 // ---------------------------------------------------------------------------
 // K2, register-resident form: every lane owns NS agent slots (slot = r*64+lane,
 // slot -> (sample g, agent i)) whose force accumulator and social-work sum stay in
@@ -1115,9 +1137,9 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         if (ok_[r] && !(half && i_[r] >= rows)) {
           const int io = 8 * sl_[r];
           R qx, qy;
-          pair_force_state<R>(k, lds_at<double>(smem, io), lds_at<double>(smem, io + PY), lds_at<double>(smem, io + VX),
-                              lds_at<double>(smem, io + VY), lds_at<double>(smem, jo), lds_at<double>(smem, jo + PY),
-                              lds_at<double>(smem, jo + VX), lds_at<double>(smem, jo + VY), qx, qy);
+          double pix, piy, vix, viy, pjx, pjy, vjx, vjy;
+          lds_pair_state<PY, VX, VY>(static_cast<uint32_t>(io), static_cast<uint32_t>(jo), pix, piy, vix, viy, pjx, pjy, vjx, vjy);
+          pair_force_state<R>(k, pix, piy, vix, viy, pjx, pjy, vjx, vjy, qx, qy);
           fx[r] += static_cast<double>(qx);
           fy[r] += static_cast<double>(qy);
           // the partner receives -q: accumulated with the opposite sign, subtracted in the agent pass
@@ -1393,9 +1415,15 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
   // one pair per lane: both agents from LDS, the force into both agents' accumulators
   auto pair_at = [&](uint32_t io, uint32_t jo) {
     R qx, qy;
-    pair_force_state<R>(k, lds_at<double>(smem, io), lds_at<double>(smem, io + PY), lds_at<double>(smem, io + VX),
-                        lds_at<double>(smem, io + VY), lds_at<double>(smem, jo), lds_at<double>(smem, jo + PY),
-                        lds_at<double>(smem, jo + VX), lds_at<double>(smem, jo + VY), qx, qy);
+    if constexpr (CAP > 0) {
+      double pix, piy, vix, viy, pjx, pjy, vjx, vjy;
+      lds_pair_state<8 * CAP, 16 * CAP, 24 * CAP>(io, jo, pix, piy, vix, viy, pjx, pjy, vjx, vjy);
+      pair_force_state<R>(k, pix, piy, vix, viy, pjx, pjy, vjx, vjy, qx, qy);
+    } else {
+      pair_force_state<R>(k, lds_at<double>(smem, io), lds_at<double>(smem, io + PY), lds_at<double>(smem, io + VX),
+                          lds_at<double>(smem, io + VY), lds_at<double>(smem, jo), lds_at<double>(smem, jo + PY),
+                          lds_at<double>(smem, jo + VX), lds_at<double>(smem, jo + VY), qx, qy);
+    }
     atomicAdd(&lds_at<double>(smem, io + FCX), static_cast<double>(qx));
     atomicAdd(&lds_at<double>(smem, io + FCY), static_cast<double>(qy));
     // j receives -q: accumulated with the opposite sign, subtracted in the agent pass
@@ -1407,14 +1435,19 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     if (n_it > 0) {
       uint32_t ia, ja, ib, jb;
       load_pair_entries(tab_i, tab_j, lane_off, ia, ja);
-      for (int it = 0; it < n_it; it += 2) {
+      int left = n_it;  // iterations still to run: a plain scalar countdown (the it < n_it form kept its state in a VGPR lane)
+      const uint16_t *ti = tab_i + WAVE, *tj = tab_j + WAVE;
+      for (; left >= 2; left -= 2, ti += 2 * WAVE, tj += 2 * WAVE) {
         wait_pair_entries(ia, ja);  // also covers the robot record issued a step ago
-        if (it + 1 < n_it) load_pair_entries(tab_i + (it + 1) * WAVE, tab_j + (it + 1) * WAVE, lane_off, ib, jb);
+        load_pair_entries(ti, tj, lane_off, ib, jb);
         pair_at(ia, ja);
-        if (it + 1 >= n_it) break;
         wait_pair_entries(ib, jb);
-        if (it + 2 < n_it) load_pair_entries(tab_i + (it + 2) * WAVE, tab_j + (it + 2) * WAVE, lane_off, ia, ja);
+        if (left > 2) load_pair_entries(ti + WAVE, tj + WAVE, lane_off, ia, ja);
         pair_at(ib, jb);
+      }
+      if (left == 1) {
+        wait_pair_entries(ia, ja);
+        pair_at(ia, ja);
       }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -29,7 +29,7 @@ def _port():
 
 def test_single_gpu_line():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--verify", "--extras",
-                        "upload,resident,cfg2,cfg2_o64", "--extra-steps", "3"], cwd=ROOT,
+                        "upload,resident,cfg2,cfg2_o64,inproc_multi", "--extra-steps", "3"], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -50,6 +50,11 @@ def test_single_gpu_line():
     assert ex["cfg2"]["value"] > 1e6 and 0 < ex["cfg2"]["roofline_executed_frac"] <= ex["cfg2"]["roofline_frac"]
     assert "64 laser points" in ex["cfg2_o64"]["workload"] and ex["cfg2_o64"]["value"] < ex["cfg2"]["value"]
     assert ex["resident_launch"]["value"] > 1e6  # informational: launch + selection fetch only
+    # sfw_multi_score_grid itself, R = 1..8 host-reduce ranks on the one device: same command, the host side does not grow with R
+    im = ex["inproc_multi"]
+    assert all(im[f"R{r}"]["cmd_vel_index"] == d["cmd_vel"]["index"] and im[f"R{r}"]["value"] > 1e6 for r in (1, 2, 4, 8))
+    assert im["R8"]["enqueue_us"] < 4 * im["R1"]["enqueue_us"] and im["R8"]["ranks"] == 8
+    assert d["scaling"] is None and d["sustained_clock_ghz"] > 1.0
     assert rf["hbm"]["unit"] == "GB/s" and rf["hbm"]["frac"] < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["all_cores"]["cores"] >= 1
@@ -60,12 +65,17 @@ def test_single_gpu_line():
 def test_two_ranks_on_one_gpu_over_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--no-cpu-baseline", "--no-extra"]
+           "--backend", "gloo", "--no-cpu-baseline", "--extras", "inproc_multi", "--inproc-workload", "cfg2"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d2 = _last_json(r.stdout)
     assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["config"]["samples_per_gpu"] == 65536
     assert len(d2["per_rank"]["social_kernel_ms"]) == 2 and min(d2["per_rank"]["exchange_us"]) > 0
+    assert len(d2["per_rank"]["executed_share"]) == 2 and all(0 < v <= 1 for v in d2["per_rank"]["executed_share"])
+    # rank 0 alone through sfw_multi_score_grid (one process, two ranks): printed next to the torchrun numbers
+    im = d2["extra"]["inproc_multi_cfg2"]
+    assert im["ranks"] == 2 and im["value"] > 1e6 and im["enqueue_us"] > 0, im
+    assert d2["extra"]["inproc_multi_target"]["ranks"] == 2
     # the same 512x256 grid scored by one process selects the same command
     r1 = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--grid", "512x256",
                          "--no-cpu-baseline", "--no-extra"], cwd=ROOT, capture_output=True, text=True, timeout=900)
