@@ -1106,11 +1106,11 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
 #pragma unroll
   for (int r = 0; r < NS; ++r) hi_[r] = 8 * (sl_[r] - i_[r] + A);
   const int wrap = 8 * A;
-  const char *rs_src = nullptr;
+  // byte offset of this lane's half record inside a row of the robot-step table (a chunk's row is < 4 GB: one VGPR)
+  uint32_t rs_off = 0;
   if (lane < 2 * Gn)
-    rs_src = reinterpret_cast<const char *>(L.rstep + static_cast<int64_t>(step_begin) * L.rstep_stride +
-                                            robot_sample_of_item(L, first_local + (lane >> 1))) + 16 * (lane & 1);
-  const int64_t rs_row_bytes = L.rstep_stride * static_cast<int64_t>(sizeof(sfw_robot_step));
+    rs_off = static_cast<uint32_t>(robot_sample_of_item(L, first_local + (lane >> 1)) * static_cast<int64_t>(sizeof(sfw_robot_step))) +
+             16u * (lane & 1);
 
   for (int step = step_begin; step < step_end; ++step) {
     // This step's robot records (32 B per sample, contiguous) go from the K1 table straight to
@@ -1118,12 +1118,12 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     // launch start together and run the same instruction stream, so a load issued where it is
     // consumed stalls every resident wave of the SIMD at once (14 % of wave time in s_waitcnt
     // at cfg2 before this, profiles/r01e).  Lane l < 2 Gn brings half (l & 1) of sample (l >> 1)'s record from
-    // its own pointer (G <= 32, plan_for), advanced by one table row per step (two VALU issues; forming the address from the item
+    // the step's table row (a scalar base) plus its own byte offset, fixed for the rollout (G <= 32, plan_for; forming the address from the item
     // tables every step cost ~90 and, at 80 VGPRs, the scratch spills around it).
     if (lane < 2 * Gn)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rs_src,
-                                       (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(s.rsb)), 16, 0, 0);
-    rs_src += rs_row_bytes;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(L.rstep + static_cast<int64_t>(step) * L.rstep_stride) + rs_off),
+          (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(s.rsb)), 16, 0, 0);
     // ---- pair pass: social forces at the pre-step state -------------------
 #pragma unroll
     for (int r = 0; r < NS; ++r) jo_[r] = 8 * sl_[r];

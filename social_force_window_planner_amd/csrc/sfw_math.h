@@ -94,8 +94,8 @@ struct poly_consts {
 __device__ __forceinline__ void rsqrt_sqrt(double x, double &rs, double &sq) {
   const double y = __builtin_amdgcn_rsq(x);
   const double h = 0.5 * x;
-  const double r = fma(-h, y * y, 1.5);  // Newton: y1 = y0 (1.5 - 0.5 x y0^2)
-  rs = y * r;
+  const double e = fma(-h, y * y, 0.5);  // Newton: y1 = y0 (1.5 - 0.5 x y0^2) = y0 + y0 (0.5 - 0.5 x y0^2): the same four
+  rs = fma(y, e, y);                     // issues with 0.5 (an inline constant) instead of 1.5 (a literal in a VGPR pair)
   sq = x * rs;
 }
 __device__ __forceinline__ double rcp_nr(double x) {
