@@ -564,15 +564,34 @@ void rest_forces(const sfw_params &p, const std::vector<std::pair<int32_t, int32
     const double wx = vel[2 * i] - vel[2 * j], wy = vel[2 * i + 1] - vel[2 * j + 1];  // velDiff (= 0)
     const double ix = p.sfm_lambda * wx + ux, iy = p.sfm_lambda * wy + uy;            // interactionVector
     const double il = std::sqrt(ix * ix + iy * iy);
+    if (!(il > 0.0)) continue;  // I = 0 (apart at exactly 1/lambda along the line): the reference divides by zero there; the kernels' term is 0
     const double ex = ix / il, ey = iy / il;                                          // interactionDirection
     double theta = std::atan2(uy, ux) - std::atan2(ey, ex);                           // angleTo, kept in (-pi, pi]
     while (theta <= -M_PI) theta += 2.0 * M_PI;
     while (theta > M_PI) theta -= 2.0 * M_PI;
-    if (theta == 0.0) continue;
-    const double B = p.sfm_gamma * il, sq = p.sfm_n * B * theta;
-    const double fa = -(theta > 0.0 ? 1.0 : -1.0) * std::exp(-dn / B - sq * sq);
-    out[2 * i] += p.sfm_force_factor_social * fa * -ey;                               // leftNormal = (-y, x)
-    out[2 * i + 1] += p.sfm_force_factor_social * fa * ex;
+    const double B = p.sfm_gamma * il;
+    if (theta != 0.0) {
+      const double sq = p.sfm_n * B * theta;
+      const double fa = -(theta > 0.0 ? 1.0 : -1.0) * std::exp(-dn / B - sq * sq);
+      out[2 * i] += p.sfm_force_factor_social * fa * -ey;                             // leftNormal = (-y, x)
+      out[2 * i + 1] += p.sfm_force_factor_social * fa * ex;
+    }
+#if SFW_SIGN_OF_ZERO
+    // ... minus what the kernels themselves apply to such a pair: their |theta| is 0 or pi by the side I points to, their
+    // exponential a 1e-12 polynomial (the difference to this libm one stays as a 1e-12 share of the term), their sign the
+    // sign bit of w x diff = fma(wx, dy, -(wy dx)) — of a ZERO here, which depends on the order the pair is taken in
+    // (v - v is +0 either way while diff changes sign).  Both K2 organisations evaluate an unordered pair once, as (a, b)
+    // with b = (a + row + 1) mod A, row < A / 2 (the last row of an even A only for a < A / 2), and give b the negative.
+    const int fwd = ((j - i) % A + A) % A, rows = A / 2;
+    const bool i_first = fwd < rows || (fwd == rows && ((A & 1) ? true : i < rows));
+    auto rev = [](double x) { return -x + 0.0; };  // b - a from a - b: the exact negative, a zero difference stays +0
+    const double cw_k = i_first ? std::fma(wx, dy, -(wy * dx)) : std::fma(rev(wx), rev(dy), -(rev(wy) * rev(dx)));
+    const double tk = (ix * ux + iy * uy) < 0.0 ? M_PI : 0.0, sk = p.sfm_n * B * tk;
+    const double s_k = std::signbit(cw_k) ? -1.0 : 1.0;
+    const double fk = -s_k * std::exp(-dn / B - sk * sk);
+    out[2 * i] -= p.sfm_force_factor_social * fk * -ey;
+    out[2 * i + 1] -= p.sfm_force_factor_social * fk * ex;
+#endif
   }
 }
 

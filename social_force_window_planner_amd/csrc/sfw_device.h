@@ -8,6 +8,13 @@
 
 #include "../../include/sfw_hip.h"
 
+// 1: the pair term's angular part takes the sign BIT of w x diff (one v_bfi_b32), also when that product is exactly zero;
+// the host-evaluated terms of such pairs (rest_forces) then include the cancellation of the kernels' own.  0: the kernels
+// keep an exact zero there (a compare and two selects per pair evaluation: round 2's form, kept for A/B).
+#ifndef SFW_SIGN_OF_ZERO
+#define SFW_SIGN_OF_ZERO 1
+#endif
+
 // Per-sample status written by the rollout kernel.
 enum : int32_t { SFW_ST_VALID = 0, SFW_ST_INVALID = 1, SFW_ST_SKIPPED = 2 };
 

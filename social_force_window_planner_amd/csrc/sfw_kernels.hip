@@ -520,7 +520,11 @@ __device__ __forceinline__ agent_consts load_agent_consts(late_launch La, bool f
 // cw = w x diff evaluated in double by the caller (exact sign in both modes).
 __device__ __forceinline__ double copysign_from(double mag, double sgn) { return __builtin_copysign(mag, sgn); }
 __device__ __forceinline__ float copysign_from(float mag, double sgn) {
+#if SFW_SIGN_OF_ZERO
+  return __builtin_copysignf(mag, static_cast<float>(sgn));  // the conversion keeps the sign bit, of zeros and of underflows too
+#else
   return __builtin_copysignf(mag, sgn < 0.0 ? -1.0f : 1.0f);
+#endif
 }
 
 template <typename R>
@@ -547,8 +551,16 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   const R t2 = l2 * (theta * theta);      // (B theta)^2 = gamma^2 |I|^2 theta^2; gamma^2 sits in c_vel / c_ang
   R ev, ea;  // Fs exp(-|diff|/B - (n' B theta)^2), Fs exp(-|diff|/B - (n B theta)^2)
   exp_fast2(k.pc, fma(k.c_vel, t2, a), fma(k.c_ang, t2, a), ev, ea);
+#if SFW_SIGN_OF_ZERO
+  // sign(theta) * exp(...): the sign BIT of cw, one v_bfi_b32.  For w x diff == 0 (relative rest, motion along the
+  // connecting line) that is the sign of a zero — as arbitrary as lightsfm's rounding noise there, but known to the host,
+  // which evaluates the reference's term for exactly these pairs of the handed-over state and takes this one back out
+  // (rest_forces, sfw_capi.hip).  Treating the zero apart cost a compare and two selects in every pair evaluation.
+  ea = copysign_from(ea, cw);
+#else
   // sign(theta) * exp(...): sign bit copied from cw, exact zero kept (relative rest)
   ea = (cw != 0.0) ? copysign_from(ea, cw) : R(0);
+#endif
   const R gx = ix * rl, gy = iy * rl;    // Ihat
   // f = -ev * Ihat - ea * leftNormal(Ihat),  leftNormal(x,y) = (-y, x)
   fx = fma(ea, gy, -(ev * gx));
