@@ -527,7 +527,9 @@ __device__ __forceinline__ float copysign_from(float mag, double sgn) {
 #endif
 }
 
-template <typename R>
+// NORM_ONLY: fx receives |f| = sqrt(ev^2 + ea^2) (Ihat and its left normal are orthonormal) and fy nothing — what
+// computeSocialWork's robot-on-person term needs (ref :692-699): no direction, no sign.
+template <typename R, bool NORM_ONLY = false>
 __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R wx, R wy, double cw, R &fx,
                                            R &fy) {
   using namespace sfwm;
@@ -551,6 +553,17 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   const R t2 = l2 * (theta * theta);      // (B theta)^2 = gamma^2 |I|^2 theta^2; gamma^2 sits in c_vel / c_ang
   R ev, ea;  // Fs exp(-|diff|/B - (n' B theta)^2), Fs exp(-|diff|/B - (n B theta)^2)
   exp_fast2(k.pc, fma(k.c_vel, t2, a), fma(k.c_ang, t2, a), ev, ea);
+  if constexpr (NORM_ONLY) {
+#if !SFW_SIGN_OF_ZERO
+    ea = (cw != 0.0) ? ea : R(0);
+#endif
+    const R q = fma(ev, ev, ea * ea);
+    R rq, nq;
+    rsqrt_sqrt(fma(R(1), q, tiny), rq, nq);
+    fx = q * rq;  // exactly 0 for q = 0
+    fy = R(0);
+    return;
+  }
 #if SFW_SIGN_OF_ZERO
   // sign(theta) * exp(...): the sign BIT of cw, one v_bfi_b32.  For w x diff == 0 (relative rest, motion along the
   // connecting line) that is the sign of a zero — as arbitrary as lightsfm's rounding noise there, but known to the host,
@@ -566,13 +579,13 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   fx = fma(ea, gy, -(ev * gx));
   fy = fma(-ev, gy, -(ea * gx));
 }
-template <typename R>
+template <typename R, bool NORM_ONLY = false>
 __device__ __forceinline__ void pair_force_state(const sfm_consts<R> &k, double pix, double piy, double vix,
                                                  double viy, double pjx, double pjy, double vjx, double vjy,
                                                  R &fx, R &fy) {
   const double dx = pjx - pix, dy = pjy - piy, wx = vix - vjx, wy = viy - vjy;
   const double cw = fma(wx, dy, -(wy * dx));
-  pair_force<R>(k, R(dx), R(dy), R(wx), R(wy), cw, fx, fy);
+  pair_force<R, NORM_ONLY>(k, R(dx), R(dy), R(wx), R(wy), cw, fx, fy);
 }
 
 // |(x, y)|, exactly 0 for the zero vector (the clamp only keeps the reciprocal root finite)
@@ -835,9 +848,9 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const agent
     if (cx * cx + cy * cy <= c.rr) s.dead[g] = 2 + step;  // >= 2: rejected by contact at `step`
     // Wp (ref :692-699): force the post-step robot alone exerts on this person
     if (ak.id != c.robot_id) {
-      R qx, qy;
-      pair_force_state<R>(k, px, py, vx, vy, rs.x, rs.y, rs.vx, rs.vy, qx, qy);
-      work = fast_norm(static_cast<double>(qx), static_cast<double>(qy));
+      R qn, unused;
+      pair_force_state<R, true>(k, px, py, vx, vy, rs.x, rs.y, rs.vx, rs.vy, qn, unused);
+      work = static_cast<double>(qn);
     }
     // desired force at the new state: with the obstacle term below, the next step's starting force
     desired_force(c, px, py, vx, vy, hg != 0, ak.gx, ak.gy, ak.gr, ak.dv, nfx, nfy);
