@@ -1724,6 +1724,7 @@ static wave_plan plan_for(int A, int64_t T, int O, int form) {
     if (sc >= best_score) { best_score = sc; best = wave_plan{1, 2, false}; }
   }
   // ... and a robot alone among laser points: the flat form spreads the points over eight lanes
+  // (4096: re-measured in round 3 at cfg2's prefix levels, 2240 / 6072 / 10948 classes: flat up to 6500 items K2 +3 %, up to 11000 +9 %)
   if (T <= 4096 && (A >= 2 || O > 0)) best = wave_plan{1, 0, true};
   if (form == SFW_K2_FLAT && (A >= 2 || O > 0)) best = wave_plan{1, 0, true};
   if (form == SFW_K2_REGISTER && A <= 2 * WAVE) best = (A <= WAVE) ? wave_plan{WAVE / A < 32 ? WAVE / A : 32, 1, false} : wave_plan{1, 2, false};
