@@ -294,6 +294,18 @@ def inproc_multi(workload_name, precision, devices, exchange, steps, warmup):
         m.close()
 
 
+def host_wait(dist, rank, key):
+    """Rank 0 releases the others through the process group's store (CPU-side wait); a barrier if there is no store."""
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            store.set(key, "1")
+        else:
+            store.wait([key])
+    except Exception:
+        dist.barrier()
+
+
 def measured_traffic(workload_name):
     """HBM bytes per launch from the committed PMC passes (profiles/r0N_traffic.json, newest first), or None."""
     for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
@@ -510,7 +522,9 @@ def main():
                     extra["inproc_multi_" + name] = inproc_multi(name, args.precision, devs, xchg, st, wu)
                 except Exception as e:  # a broken RCCL install must not take the headline line down
                     extra["inproc_multi_" + name] = {"error": repr(e)}
-        dist.barrier()
+        # the others wait on the HOST (a key of the rendezvous store): a collective would park a spinning RCCL kernel on
+        # every device rank 0 is about to use
+        host_wait(dist, rank, "sfw_inproc_multi_done")
     if rank == 0 and world == 1 and not args.resident:
         job = GridJob(args.workload, args.precision, 0, 1, local_rank)
         if args.verify:

@@ -98,3 +98,30 @@ def test_all_invalid_everywhere():
     r, k = multi_gpu.lexicographic_min([(np.inf,) * 4, (np.inf,) * 4])
     assert r is None and k is None
     assert multi_gpu.cmd_from_key(None, 9, [0.0], [0.0]) == (0.0, 0.0, -1)
+
+
+def _wait_worker(rank, world, port, out_dir):
+    import time
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+
+        t0 = time.perf_counter()
+        if rank == 0:
+            time.sleep(0.6)  # rank 0 alone drives the in-process multi-device run
+        bench.host_wait(dist, rank, "sfw_test_key")
+        np.save(os.path.join(out_dir, f"wait_{rank}.npy"), np.array([time.perf_counter() - t0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_other_ranks_wait_on_the_host_while_rank0_works(tmp_path):
+    """bench.py --gpus N: while rank 0 scores through sfw_multi_score_grid on all N devices the other ranks wait on a
+    key of the rendezvous store (no collective, hence no RCCL kernel parked on the devices rank 0 is using)."""
+    world = 3
+    mp.spawn(_wait_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    waits = [float(np.load(tmp_path / f"wait_{r}.npy")[0]) for r in range(world)]
+    assert all(w >= 0.55 for w in waits[1:]), waits
