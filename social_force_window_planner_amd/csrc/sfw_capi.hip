@@ -1063,6 +1063,10 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
     off.push_back(static_cast<int32_t>(mem.size()));
   }
   const int n_mem = off.back();
+  // the set has to fit one wave's LDS allocation whatever the grid (the flat form of one sample is the smallest): refused
+  // here, before the all-pairs scan below and long before a launch
+  if (A > 0 && sfw_social_lds_bytes(A, O, static_cast<int>(ids.size()), n_mem, 1, SFW_K2_FLAT) > 160 * 1024)
+    return fail(h, SFW_ERR_UNSUPPORTED, "set_agents: agent/obstacle set does not fit the 160 KiB LDS of one CU");
   if (mem.empty()) mem.push_back(0);
   // host blob (uploaded with the next stage): pos | vel | const | obstacles | grp | off | mem
   auto up16 = [](size_t b) { return (b + 15) & ~size_t(15); };

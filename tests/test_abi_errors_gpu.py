@@ -191,7 +191,7 @@ def test_non_finite_inputs_are_refused(hip_mod):
 
 def test_unsupported_agent_sets(hip_mod):
     """What the device cannot (or, for parity, must not) take is SFW_ERR_UNSUPPORTED, not a failed launch: more agents
-    than one wave's LDS holds, more than the 16-bit plane offsets of the pair table reach, and a person that can never
+    than one wave's LDS holds (about 2000), more than the 16-bit plane offsets of the pair table reach, and a person that can never
     move (desired_velocity <= 0: at exact relative rest with its like at every step)."""
     from social_force_window_planner_amd.planner import SfwError
 
@@ -207,20 +207,19 @@ def test_unsupported_agent_sets(hip_mod):
     agents[3].desired_velocity = 1.0
     agents[0].desired_velocity = 0.0  # the robot is not integrated by the social-force model: anything goes
     assert L.sfw_set_agents(g._h, C.addressof(agents), n, None, 0) == SFW_OK
-    for count, where in ((9000, "set_agents"), (3000, "launch")):
+    for count, where in ((9000, "set_agents"), (3000, "set_agents"), (1500, "ok")):
         many = (SfwAgent * count)()
         for i in range(count):
             a = many[i]
             a.x, a.y, a.vx, a.vy = 3.0 + 0.001 * i, 2.0 + 0.0013 * (i % 97), 0.1, 1e-5 * i
             a.goal_x, a.goal_y, a.goal_radius, a.desired_velocity, a.radius, a.has_goal, a.id, a.group_id = 9.0, 9.0, 0.35, 1.0, 0.35, 1, i, -1
         rc = L.sfw_set_agents(g._h, C.addressof(many), count, None, 0)
-        if where == "set_agents":
-            assert rc == SFW_ERR_UNSUPPORTED
-        else:
+        if where == "set_agents":   # refused before the all-pairs scan of the set and long before a launch
+            assert rc == SFW_ERR_UNSUPPORTED and (b"LDS" in L.sfw_last_error(g._h) or b"8190" in L.sfw_last_error(g._h))
+        else:                       # 1500 agents fit (flat form, run-time plane capacity): scored
             assert rc == SFW_OK
-            with pytest.raises(SfwError) as e:
-                g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
-            assert e.value.status == SFW_ERR_UNSUPPORTED and "LDS" in str(e.value)
+            c, b = g.score_grid(scene.robot_state, scene.linvels[:2], scene.angvels[:3], scene.goal_args)
+            assert np.all(np.isfinite(c))
     g.load_scene(scene)
     c, b = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
     assert (c >= 0).any()

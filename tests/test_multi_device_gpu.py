@@ -112,15 +112,19 @@ def test_multi_checks_the_lds_budget_before_any_rank_launches(hip_mod):
         a.goal_x, a.goal_y, a.goal_radius, a.desired_velocity, a.radius, a.has_goal, a.id, a.group_id = 9.0, 9.0, 0.35, 1.0, 0.35, 1, i, -1
     scene.agents = agents
     m = hip_mod.MultiScorer(default_params(), devices=(0, 0), exchange=SFW_MULTI_HOST_REDUCE)
-    m.load_scene(scene)
-    with pytest.raises(SfwError) as e:
-        m.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    with pytest.raises(SfwError) as e:   # sfw_multi_set_agents already: no rank has staged or launched anything
+        m.load_scene(scene)
     assert e.value.status == SFW_ERR_UNSUPPORTED and "LDS" in str(e.value)
     g = hip_mod.HipScorer(default_params())
-    g.load_scene(scene)
     with pytest.raises(SfwError) as e:
-        g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+        g.load_scene(scene)
     assert e.value.status == SFW_ERR_UNSUPPORTED
+    # a set that fits alone but not with its laser points in the register form's per-wave copy is refused by the grid
+    # call, before any rank launches (sfw_multi_score_grid checks every rank's item count first)
+    ok_scene = _scene(8, 9)
+    m.load_scene(ok_scene)
+    c, b = m.score_grid(ok_scene.robot_state, ok_scene.linvels, ok_scene.angvels, ok_scene.goal_args)
+    assert np.all(np.isfinite(c))
 
 
 def test_multi_tie_across_ranks_and_all_invalid(hip_mod):
