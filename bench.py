@@ -474,7 +474,7 @@ def main():
         "cmd_vel": {"vx": res["best"]["vx"], "vtheta": res["best"]["vtheta"], "cost": res["best"]["cost"],
                     "index": res["best"]["index"], "n_valid": res["best"]["n_valid"]},
         "roofline": roofline_for(job, res["k2_ms"], args.precision),
-        # shader clock the last social-force launch really ran at (wave 0's s_memtime / s_memrealtime): boxes and thermal
+        # shader clock the last social-force launch really ran at (a wave's own s_memtime / s_memrealtime): boxes and thermal
         # states differ by ~10 %, kernel times of different runs are only comparable next to it
         "sustained_clock_ghz": res["clock_ghz"],
     }

@@ -287,7 +287,7 @@ int sfw_set_timing(sfw_handle h, int32_t enabled);
  * timing was on): which = 0 whole launch, 1 rollout kernels, 2 social-force
  * kernel, 3 argmin. */
 int sfw_last_launch_ms(sfw_handle h, int32_t which, float *ms_out);
-/* Shader clock (GHz) the social-force kernel of the most recent timed sfw_grid_launch really ran at: wave 0 of the
+/* Shader clock (GHz) the social-force kernel of the most recent timed sfw_grid_launch really ran at: the middle wave of the
  * launch over the samples reads the core-clock and the constant-rate counters when it starts and when it ends.
  * 0.0 when there was nothing to sample (no agents).  Boxes and thermal states differ by ~10 %: a kernel time is
  * only comparable across runs next to this number.  SFW_ERR_STATE unless timing was on. */

@@ -141,7 +141,7 @@ struct sfw_launch {
   // optional Trajectory-points dump (x,y,theta per pre-step pose) of the chunk's samples
   double *points;        // nullable, chunk_count x S x 3 doubles
   int32_t *n_points;     // nullable, chunk_count ints
-  // measurement only (sfw_set_timing): block 0 of a K2 launch leaves {s_memtime, s_memrealtime} at its start in [0..1]
+  // measurement only (sfw_set_timing): the middle block of a K2 launch leaves {s_memtime, s_memrealtime} at its start in [0..1]
   // and at its end in [2..3]; their ratio is the shader clock the kernel really ran at.  Nullable.
   unsigned long long *clock_probe;
 };

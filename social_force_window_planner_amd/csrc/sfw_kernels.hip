@@ -466,12 +466,12 @@ __device__ __forceinline__ late_launch late_args() {
   return static_cast<late_launch>(p);  // sfw_launch is the first kernel argument: offset 0 of the segment
 }
 
-// Measurement aid (sfw_set_timing): wave 0 of a K2 launch records the shader-clock counter (s_memtime) and the
+// Measurement aid (sfw_set_timing): the middle wave of a K2 launch (wave 0 is the never-scored (0,0) sample) records the shader-clock counter (s_memtime) and the
 // constant-rate counter (s_memrealtime) when it starts and when it ends; the host turns the two differences into the
 // clock the kernel sustained (boxes differ by ~10 %: a kernel time means little without it).  Written straight to
 // memory: nothing is held in registers across the rollout.
 __device__ __forceinline__ void clock_probe(int which) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (blockIdx.x != gridDim.x / 2 || threadIdx.x != 0) return;
   unsigned long long *const p = late_args()->clock_probe;
   if (!p) return;
   p[2 * which] = __builtin_readcyclecounter();

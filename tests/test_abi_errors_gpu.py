@@ -110,6 +110,17 @@ def test_timing_is_opt_in(hip_mod):
     parts = [g.last_launch_ms(k) for k in (1, 2, 3)]
     assert total > 0 and all(p >= 0 for p in parts) and sum(parts) <= total * 1.05
     assert L.sfw_last_launch_ms(g._h, 7, C.byref(ms)) == SFW_ERR_INVALID_ARG
+    # the shader clock a wave of the social-force launch measured for itself (s_memtime against s_memrealtime)
+    assert 1.0 < g.sustained_clock_ghz() < 2.6
+    g.set_timing(False)
+    g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    ghz = C.c_double()
+    assert L.sfw_last_clock_ghz(g._h, C.byref(ghz)) == SFW_ERR_STATE
+    # no agents: no social-force launch, nothing sampled
+    g.set_timing(True)
+    g.set_agents((SfwAgent * 0)())
+    g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert g.sustained_clock_ghz() == 0.0
 
 
 def test_world_changes_between_stage_and_launch(oracle_mod, hip_mod):
