@@ -149,7 +149,16 @@ class GridJob:
         self.scorer = HipScorer(default_params(precision=prec, **self.params_kw), device=device)
         self.scorer.set_timing(True)  # per-kernel HIP events (on the handle's stream) for the roofline object
         self.scorer.load_scene(self.scene)
-        self.row0, row1 = multi_gpu.shard_rows(w.nv, rank, world)
+        if scaling == "strong" and world > 1:
+            # one grid cut over the ranks: contiguous blocks of equal PLANNED work (sfw_plan_row_blocks, the cut
+            # sfw_multi_score_grid makes too) — the shared-prefix tree saves another share of the steps in every velocity range
+            from social_force_window_planner_amd.planner import plan_row_blocks
+
+            cuts = plan_row_blocks(lin_all, ang, self.scene.robot_state, self.scene.goal_args, w.sim_time, w.n_steps,
+                                   w.n_people + 1, world)
+            self.row0, row1 = int(cuts[rank]), int(cuts[rank + 1])
+        else:
+            self.row0, row1 = multi_gpu.shard_rows(w.nv, rank, world)
         self.lin = lin_all[self.row0:row1]
         self.ang = ang
         self.index_base = self.row0 * len(self.ang)

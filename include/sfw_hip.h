@@ -270,6 +270,14 @@ int sfw_plan_shared_prefix(const double *linvels, int32_t nv,
                            int32_t n_agents, int32_t *level_ends,
                            int64_t *level_classes, int32_t cap,
                            int32_t *n_levels);
+/* Contiguous blocks of linvel rows of about equal PLANNED work for R ranks (host only): row0[0..R], rank r takes rows
+ * [row0[r], row0[r+1]).  The share of steps the shared-prefix tree saves differs along the row axis (BASELINE cfg5 cut
+ * into 8 equal blocks integrates 64..76 % of its steps per block), so equal row counts are unequal work; the cuts follow
+ * the planned class-steps instead.  Equal row counts when nothing is shared (fewer than 4096 samples per rank, fewer
+ * than two agents).  sfw_multi_score_grid cuts this way; multi-process callers use it to agree on the same cut. */
+int sfw_plan_row_blocks(const double *linvels, int32_t nv, const double *angvels, int32_t nw, double vx0,
+                        double vtheta0, double acc_x, double acc_theta, double sim_time, int32_t num_steps,
+                        int32_t n_agents, int32_t R, int32_t *row0);
 /* Tuning / test knob: which organisation the social-force kernel's waves use.  SFW_K2_AUTO (default) picks
  * per launch by agent and item count; SFW_K2_REGISTER / SFW_K2_FLAT force one wherever it exists for the
  * agent count (register: A <= 128; flat: A >= 2, or laser points).  The organisations are bit-identical in
@@ -321,8 +329,9 @@ void *sfw_stream(sfw_handle h);
  * The reference plugin is ONE process (sfw_plugin.xml:1-9; computeVelocityCommands,
  * src/sfw_planner_node.cpp:220-331), so a host that wants the (v,w) grid on several
  * MI355X drives them from there: one sfw_handle per listed device, the linvel rows
- * (the OUTER loop of src/sfw_planner.cpp:345) split into contiguous blocks
- * [r*nv/R, (r+1)*nv/R), world state replicated by each handle's own upload, and the
+ * (the OUTER loop of src/sfw_planner.cpp:345) split into R contiguous blocks of equal
+ * planned work (sfw_plan_row_blocks; [r*nv/R, (r+1)*nv/R) when the shared-prefix rollout
+ * has nothing to share), world state replicated by each handle's own upload, and the
  * winner picked by ONE ncclAllReduce(min) over xGMI of an [R,5] double table in which
  * rank r fills its own row (sfw_best_key + n_valid) and +inf elsewhere — the
  * lexicographic row minimum is the reference's selection order (:394-414).  RCCL is
@@ -350,6 +359,8 @@ int sfw_multi_set_agents(sfw_multi_handle m, const sfw_agent *agents, int32_t A,
 int sfw_multi_score_grid(sfw_multi_handle m, const sfw_robot_state *rs, const double *linvels, int32_t nv,
                          const double *angvels, int32_t nw, const sfw_goal_args *args, double *costs_out,
                          sfw_best *best_out);
+/* The block of rows rank r scored in the last sfw_multi_score_grid. */
+int sfw_multi_rank_rows(sfw_multi_handle m, int32_t r, int32_t *first_row, int32_t *n_rows);
 /* Host wall-clock of the last call's phases, microseconds: which = 0 stage+launch of all ranks (enqueue),
  * 1 exchange (enqueue of the all-reduce + fetch of the table, i.e. until every rank's kernels are done),
  * 2 cost-vector fetches. */

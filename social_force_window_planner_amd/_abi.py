@@ -161,6 +161,7 @@ EXPORTED_SYMBOLS = (
     "sfw_grid_fetch",
     "sfw_grid_plan_info",
     "sfw_plan_shared_prefix",
+    "sfw_plan_row_blocks",
     "sfw_set_k2_form",
     "sfw_set_timing",
     "sfw_last_launch_ms",
@@ -179,6 +180,7 @@ EXPORTED_SYMBOLS = (
     "sfw_multi_set_footprint",
     "sfw_multi_set_agents",
     "sfw_multi_score_grid",
+    "sfw_multi_rank_rows",
     "sfw_multi_last_us",
     "sfw_multi_grid_points",
 )

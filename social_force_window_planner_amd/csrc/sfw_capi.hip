@@ -423,6 +423,45 @@ std::vector<int> choose_levels(const prefix_classes &pc, int64_t T, int S, doubl
   return steps;
 }
 
+// Row blocks of (about) equal PLANNED work for R ranks.  A block's work is its class-steps through the shared-prefix
+// levels plus its samples' remaining steps, and the share of steps the tree saves differs along the row axis (rows are
+// ordered by target velocity: cfg5 cut into 8 equal blocks integrates 64 %..76 % of its steps per block).  With the
+// levels of the whole grid's plan every row gets a weight — for each level, (steps of the level) x (column classes) if
+// the row opens a new row class at that level, plus nw x (S - split) for its samples' own steps — and the cuts go where
+// the running sum passes r/R of the total.  Equal row counts when nothing is shared.  Each rank still makes its own plan
+// for its block; costs do not depend on the cut.
+void plan_row_blocks(const std::vector<double> &lin, const std::vector<double> &ang, double vx0, double vth0, double acc_x,
+                     double acc_theta, double dt, int S, int A, int R, int form, std::vector<int32_t> &row0) {
+  const int64_t nv = static_cast<int64_t>(lin.size()), nw = static_cast<int64_t>(ang.size());
+  row0.assign(static_cast<size_t>(R) + 1, 0);
+  for (int r = 0; r <= R; ++r) row0[static_cast<size_t>(r)] = static_cast<int32_t>((static_cast<int64_t>(r) * nv) / R);
+  if (R <= 1 || A < 2 || S < 2 || (nv / R) * nw < 4096) return;
+  prefix_classes pc;
+  classes_of_grid(pc, lin, ang, vx0, vth0, acc_x, acc_theta, dt, S);
+  // the levels of the WHOLE grid's plan (its class counts are the whole grid's): the blocks' own plans differ in detail,
+  // the relative weights along the row axis do not
+  const std::vector<int> steps = choose_levels(pc, nv * nw, S, static_cast<double>(sfw_samples_per_wave(A, (nv / R) * nw, form)));
+  if (steps.empty()) return;
+  std::vector<double> w(static_cast<size_t>(nv), static_cast<double>(nw) * (S - steps.back()));
+  int prev = 0;
+  for (int p : steps) {
+    const std::vector<int32_t> &rc = pc.rows.c[std::min<size_t>(static_cast<size_t>(p), pc.rows.c.size()) - 1];
+    const double per_class = static_cast<double>(pc.n_cols_at(p)) * (p - prev);
+    for (int64_t i = 0; i < nv; ++i)
+      if (i == 0 || rc[static_cast<size_t>(i)] != rc[static_cast<size_t>(i - 1)]) w[static_cast<size_t>(i)] += per_class;
+    prev = p;
+  }
+  double total = 0.0;
+  for (double v : w) total += v;
+  double run = 0.0;
+  int r = 1;
+  for (int64_t i = 0; i < nv && r < R; ++i) {
+    run += w[static_cast<size_t>(i)];
+    while (r < R && run >= total * r / R) row0[static_cast<size_t>(r++)] = static_cast<int32_t>(i + 1);
+  }
+  for (; r < R; ++r) row0[static_cast<size_t>(r)] = static_cast<int32_t>(nv);
+}
+
 // Decide the levels of the staged grid's shared-prefix tree and lay the class tables out per chunk of
 // whole rows.
 int plan_prefix(sfw_handle h, int64_t chunk, int S) {
@@ -1228,6 +1267,18 @@ int sfw_plan_shared_prefix(const double *linvels, int32_t nv, const double *angv
   return SFW_OK;
 }
 
+int sfw_plan_row_blocks(const double *linvels, int32_t nv, const double *angvels, int32_t nw, double vx0, double vtheta0,
+                        double acc_x, double acc_theta, double sim_time, int32_t num_steps, int32_t n_agents, int32_t R,
+                        int32_t *row0) {
+  if (!linvels || !angvels || nv <= 0 || nw <= 0 || num_steps < 1 || R < 1 || !row0) return SFW_ERR_INVALID_ARG;
+  if (!all_finite(linvels, static_cast<size_t>(nv)) || !all_finite(angvels, static_cast<size_t>(nw))) return SFW_ERR_INVALID_ARG;
+  const std::vector<double> lin(linvels, linvels + nv), ang(angvels, angvels + nw);
+  std::vector<int32_t> cuts;
+  plan_row_blocks(lin, ang, vx0, vtheta0, acc_x, acc_theta, sim_time / num_steps, num_steps, n_agents, R, SFW_K2_AUTO, cuts);
+  std::memcpy(row0, cuts.data(), sizeof(int32_t) * (static_cast<size_t>(R) + 1));
+  return SFW_OK;
+}
+
 int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out) {
   if (!h || !out) return SFW_ERR_INVALID_ARG;
   if (!h->staged) return fail(h, SFW_ERR_STATE, "grid_plan_info before grid_stage");
@@ -1694,12 +1745,19 @@ int sfw_multi_score_grid(sfw_multi_handle m, const sfw_robot_state *rs, const do
   m->ang.assign(angvels, angvels + nw);
   m->nv = nv;
   m->nw = nw;
-  m->row0.assign(static_cast<size_t>(R) + 1, 0);
-  for (int r = 0; r <= R; ++r) m->row0[static_cast<size_t>(r)] = static_cast<int32_t>((static_cast<int64_t>(r) * nv) / R);  // ref :345: rows are the outer axis
   const double t0 = now_us();
+  sfw_handle h0 = m->h[0];
+  if (!all_finite(linvels, static_cast<size_t>(nv)) || !all_finite(angvels, static_cast<size_t>(nw)) || !all_finite(&rs->x, 6) ||
+      !all_finite(&args->acc_x, 5))
+    return mfail(m, SFW_ERR_INVALID_ARG, "multi_score_grid: non-finite robot state, goal argument or sample velocity");
+  {  // ref :345: rows are the outer axis — contiguous blocks of equal planned work (equal row counts when nothing is shared)
+    const int S = num_steps_of(h0->params);
+    const bool sharing = h0->prefix_env.empty() || h0->prefix_env[0] != 0;
+    plan_row_blocks(m->lin, m->ang, rs->vx, rs->vtheta, args->acc_x, args->acc_theta, h0->params.sim_time / S, S, sharing ? h0->A : 0, R,
+                    h0->k2_form, m->row0);
+  }
   // (0) what is the same for every rank, once: the agent set must fit a wave's LDS for every rank's item count
   // before anything is launched anywhere, and the classes of the column axis (every rank scores all nw columns)
-  sfw_handle h0 = m->h[0];
   for (int r = 0; r < R; ++r) {
     const int64_t items = static_cast<int64_t>(m->row0[static_cast<size_t>(r) + 1] - m->row0[static_cast<size_t>(r)]) * nw;
     if (items > 0 && h0->A > 0 && sfw_social_lds_bytes(h0->A, h0->O, h0->NG, h0->n_grp_mem, items, h0->k2_form) > 160 * 1024)
@@ -1826,6 +1884,14 @@ int sfw_multi_score_grid(sfw_multi_handle m, const sfw_robot_state *rs, const do
     }
   }
   m->scored = true;
+  return SFW_OK;
+}
+
+int sfw_multi_rank_rows(sfw_multi_handle m, int32_t r, int32_t *first_row, int32_t *n_rows) {
+  if (!m || r < 0 || r >= m->R || !first_row || !n_rows) return SFW_ERR_INVALID_ARG;
+  if (!m->scored) return mfail(m, SFW_ERR_STATE, "multi_rank_rows before multi_score_grid");
+  *first_row = m->row0[static_cast<size_t>(r)];
+  *n_rows = m->row0[static_cast<size_t>(r) + 1] - m->row0[static_cast<size_t>(r)];
   return SFW_OK;
 }
 

@@ -355,10 +355,12 @@ bool SFWPlanner::getTrajectories(std::vector<Trajectory> &out) {
   std::vector<double> pts(static_cast<size_t>(3) * S * T);
   std::vector<int32_t> n(static_cast<size_t>(T));
   if (multi_) {  // every rank dumps its own block of rows
-    const int64_t nv = static_cast<int64_t>(linvels_.size()), R = sfw_multi_ranks(multi_);
-    for (int64_t r = 0; r < R; ++r) {
-      const int64_t lo = r * nv / R * nw, cnt = (r + 1) * nv / R * nw - lo;
-      if (cnt > 0 && sfw_grid_points_batch(sfw_multi_rank_handle(multi_, static_cast<int32_t>(r)), 0, cnt,
+    const int32_t R = sfw_multi_ranks(multi_);
+    for (int32_t r = 0; r < R; ++r) {
+      int32_t first = 0, rows = 0;
+      if (sfw_multi_rank_rows(multi_, r, &first, &rows) != SFW_OK) return false;
+      const int64_t lo = static_cast<int64_t>(first) * nw, cnt = static_cast<int64_t>(rows) * nw;
+      if (cnt > 0 && sfw_grid_points_batch(sfw_multi_rank_handle(multi_, r), 0, cnt,
                                            pts.data() + static_cast<size_t>(lo) * 3 * S, n.data() + lo) != SFW_OK)
         return false;
     }

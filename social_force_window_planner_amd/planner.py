@@ -108,6 +108,11 @@ def lib():
         L.sfw_multi_score_grid.argtypes = [vp, C.POINTER(SfwRobotState), vp, C.c_int32, vp, C.c_int32,
                                            C.POINTER(SfwGoalArgs), vp, C.POINTER(SfwBest)]
         L.sfw_multi_last_us.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
+        L.sfw_multi_rank_rows.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.sfw_plan_row_blocks.argtypes = [vp, C.c_int32, vp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                          C.c_double, C.c_int32, C.c_int32, C.c_int32, vp]
+        L.sfw_plan_shared_prefix.argtypes = [vp, C.c_int32, vp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                             C.c_double, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.POINTER(C.c_int32)]
         L.sfw_multi_grid_points.argtypes = [vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32)]
         _lib = L
     return _lib
@@ -269,6 +274,37 @@ class HipScorer:
         return pts[: min(n.value, points_cap)].copy()
 
 
+def plan_row_blocks(linvels, angvels, robot_state, goal_args, sim_time, num_steps, n_agents, n_ranks):
+    """sfw_plan_row_blocks (host only, no device): row offsets [R + 1] of the contiguous blocks of equal planned work."""
+    lin, ang = _f64(linvels), _f64(angvels)
+    row0 = np.zeros(n_ranks + 1, dtype=np.int32)
+    rc = lib().sfw_plan_row_blocks(lin.ctypes.data, len(lin), ang.ctypes.data, len(ang), robot_state[3], robot_state[5],
+                                   goal_args[0], goal_args[2], sim_time, num_steps, n_agents, n_ranks, row0.ctypes.data)
+    if rc != SFW_OK:
+        raise SfwError(rc, "sfw_plan_row_blocks")
+    return row0
+
+
+def planned_share(linvels, angvels, robot_state, goal_args, sim_time, num_steps, n_agents):
+    """Share of the algorithmic sample-steps the plan of this grid would integrate (sfw_plan_shared_prefix, host only)."""
+    lin, ang = _f64(linvels), _f64(angvels)
+    ends, cls, n = np.zeros(64, dtype=np.int32), np.zeros(64, dtype=np.int64), C.c_int32()
+    rc = lib().sfw_plan_shared_prefix(lin.ctypes.data, len(lin), ang.ctypes.data, len(ang), robot_state[3], robot_state[5],
+                                      goal_args[0], goal_args[2], sim_time, num_steps, n_agents, ends.ctypes.data,
+                                      cls.ctypes.data, 64, C.byref(n))
+    if rc != SFW_OK:
+        raise SfwError(rc, "sfw_plan_shared_prefix")
+    k = min(n.value, 64)
+    if k == 0:
+        return 1.0
+    total = len(lin) * len(ang) * num_steps
+    prev, class_steps = 0, 0
+    for l in range(k):
+        class_steps += int(cls[l]) * int(ends[l] - prev)
+        prev = int(ends[l])
+    return (class_steps + len(lin) * len(ang) * (num_steps - prev)) / total
+
+
 def plan_info_of_rank(multi, r):
     """sfw_grid_plan_info of rank r's handle of a MultiScorer (after a score_grid)."""
     info = SfwPlanInfo()
@@ -334,6 +370,12 @@ class MultiScorer:
                                                len(ang), C.byref(ga), costs.ctypes.data if want_costs else None,
                                                C.byref(best)), "sfw_multi_score_grid")
         return costs, best.as_dict()
+
+    def rank_rows(self, r):
+        """(first row, rows) of rank r in the last score_grid."""
+        a, b = C.c_int32(), C.c_int32()
+        self._check(lib().sfw_multi_rank_rows(self._m, r, C.byref(a), C.byref(b)), "sfw_multi_rank_rows")
+        return a.value, b.value
 
     def last_us(self):
         out = []

@@ -44,10 +44,10 @@ def test_multi_equals_single(hip_mod, devices, exchange, nv, nw):
         assert np.array_equal(m.grid_points(idx), g.grid_points(idx))
 
 
-@pytest.mark.parametrize("nv,nw,R", [(256, 64, 4), (64, 256, 8), (130, 96, 8), (5, 9, 8)])
+@pytest.mark.parametrize("nv,nw,R", [(256, 128, 4), (64, 256, 8), (130, 96, 8), (5, 9, 8)])
 def test_many_ranks_share_the_column_plan(hip_mod, nv, nw, R):
     """R = 4 / 8 ranks staged and launched by the handle's worker threads, the shared-prefix classes of the column
-    axis computed once for all of them (256 x 64 over 4 ranks: 4096 samples per rank, every rank plans a prefix
+    axis computed once for all of them (256 x 128 over 4 ranks: ~8192 samples per rank, every rank plans a prefix
     tree): costs, selection and plan-dependent results bit-equal to one sfw_score_grid; 5 rows over 8 ranks: three
     ranks hold nothing."""
     scene = _scene(nv, nw, n_people=12, seed=72)
@@ -60,9 +60,17 @@ def test_many_ranks_share_the_column_plan(hip_mod, nv, nw, R):
     for _ in range(3):  # the workers are reused call after call
         c2, b2 = m.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
         assert np.array_equal(c1, c2) and b1 == b2
+    # contiguous blocks covering the grid; of equal planned work (sfw_plan_row_blocks) where the prefix tree shares steps
+    blocks = [m.rank_rows(r) for r in range(R)]
+    assert blocks[0][0] == 0 and sum(n for _, n in blocks) == nv
+    assert all(blocks[r][0] + blocks[r][1] == blocks[r + 1][0] for r in range(R - 1))
     if (nv // R) * nw >= 4096:
-        info = hip_mod.plan_info_of_rank(m, 1)
-        assert info["levels"] > 0
+        assert any(hip_mod.plan_info_of_rank(m, r)["levels"] > 0 for r in range(R))  # (a block cut below 4096 samples plans none)
+        cuts = hip_mod.plan_row_blocks(scene.linvels, scene.angvels, scene.robot_state, scene.goal_args, 1.0, 40,
+                                       len(scene.agents), R)
+        assert [b[0] for b in blocks] == list(cuts[:-1])
+    else:
+        assert [b[0] for b in blocks] == [r * nv // R for r in range(R)]
     # another robot state and another column axis: the lent column classes must not outlive their call
     rs2 = (0.0, 0.0, 0.0, float(np.float32(0.1)), 0.0, float(np.float32(0.2)))
     ang2 = scene.angvels[::-1].copy()
