@@ -86,6 +86,32 @@ def standing_scene(seed):
     return sc
 
 
+def collinear_scene(seed):
+    """Motion exactly along the connecting line (round 3): grid-aligned people walking towards each other (lightsfm's theta
+    is rounding noise around 0, like relative rest) and apart faster than 1 / lambda (theta = +-pi), the robot on the line of
+    two of them, one pair on a diagonal.  w x diff == 0 for all these pairs; the fixture pins what the oracle (this image's
+    libm) makes of them."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=8, nw=9, n_people=14, seed=seed)
+    sc = syn.make_scene(w)
+
+    def put(i, x, y, vx, vy):
+        a = sc.agents[i]
+        a.x, a.y, a.vx, a.vy = x, y, vx, vy
+        a.goal_x, a.goal_y = x + 2.0 * vx, y + 2.0 * vy
+
+    put(1, 2.0, 1.0, -0.8, 0.0)
+    put(2, 4.0, 1.0, 0.8, 0.0)
+    put(3, -2.0, -1.5, 0.6, 0.0)
+    put(4, -0.5, -1.5, -0.6, 0.0)
+    put(5, -3.0, 2.0, 0.0, 0.7)
+    put(6, -3.0, 0.5, 0.0, -0.9)
+    put(7, 3.0, 0.0, -0.9, 0.0)
+    put(8, -2.5, 0.0, -1.0, 0.0)
+    put(9, 1.5, 2.5, 0.25, 0.25)
+    put(10, 2.5, 3.5, 0.75, 0.75)
+    return sc
+
+
 def cases():
     yield "cfg1", syn.make_scene("cfg1"), {}
     for n in (0, 1, 5):
@@ -98,6 +124,7 @@ def cases():
     yield "blocked", blocked_scene(23), {}
     yield "groups_obs", grouped_scene(25), {}
     yield "standing_people", standing_scene(501), {}
+    yield "collinear_walkers", collinear_scene(611), {}
     w = dataclasses.replace(syn.WORKLOADS["cfg3"], nv=5, nw=6, map_size=200, seed=24)
     yield "cfg3_5x6_yamlweights", syn.make_scene(w), dict(social_weight=2.0, vel_weight=0.8, angle_weight=0.6,
                                                           max_vel_x=0.8, robot_radius=0.4)

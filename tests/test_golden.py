@@ -27,7 +27,7 @@ def _check(fx, costs, best, rtol):
 
 def test_fixture_inventory():
     assert {"cfg1", "ref5x9_n0", "ref5x9_n1", "ref5x9_n5", "cfg2_12x12_obs8", "crowd70_point", "blocked",
-            "cfg3_5x6_yamlweights", "groups_obs", "standing_people"} <= set(gu.names())
+            "cfg3_5x6_yamlweights", "groups_obs", "standing_people", "collinear_walkers"} <= set(gu.names())
 
 
 @pytest.mark.parametrize("name", gu.names())
