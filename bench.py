@@ -13,10 +13,10 @@ sfw_score_grid is made of.  The world state (costmap, footprint, agents) is resi
 library before the timed region starts.  Default workload: the north-star target
 configuration (256 x 256 samples, 50 pedestrians, 40 steps).
 
-N > 1 (one process per GPU under torch.distributed.run): every rank scores one
-workload-sized block of linvel rows of an N-times taller grid (weak scaling; rows are the
-outer, sharded axis, ref :345) and one all-reduce(min) of the [N,4] f64 key table per step
-picks the global best.  Every N also reports BASELINE.json config 5 (4096 x 4096, 100
+N > 1 (one process per GPU under torch.distributed.run): the ranks share an N-times taller
+grid (weak scaling; rows are the outer, sharded axis, ref :345) — contiguous blocks of linvel
+rows of equal planned work, about one workload-sized block each — and one all-reduce(min) of the
+[N,4] f64 key table per step picks the global best.  Every N also reports BASELINE.json config 5 (4096 x 4096, 100
 pedestrians) sharded over the N ranks under extra.cfg5_strong (strong scaling).
 
 Rank 0 prints ONE JSON line.
@@ -149,9 +149,10 @@ class GridJob:
         self.scorer = HipScorer(default_params(precision=prec, **self.params_kw), device=device)
         self.scorer.set_timing(True)  # per-kernel HIP events (on the handle's stream) for the roofline object
         self.scorer.load_scene(self.scene)
-        if scaling == "strong" and world > 1:
-            # one grid cut over the ranks: contiguous blocks of equal PLANNED work (sfw_plan_row_blocks, the cut
-            # sfw_multi_score_grid makes too) — the shared-prefix tree saves another share of the steps in every velocity range
+        if world > 1:
+            # the grid — cfg5 itself (strong scaling) or the N-times taller target grid (weak scaling) — cut over the ranks into
+            # contiguous blocks of equal PLANNED work (sfw_plan_row_blocks, the cut sfw_multi_score_grid makes too): the
+            # shared-prefix tree saves another share of the steps in every velocity range, equal row counts are unequal work
             from social_force_window_planner_amd.planner import plan_row_blocks
 
             cuts = plan_row_blocks(lin_all, ang, self.scene.robot_state, self.scene.goal_args, w.sim_time, w.n_steps,
@@ -231,17 +232,17 @@ def run_config(workload_name, precision, steps, warmup, ctx, scaling="weak", res
         tot = torch.tensor([float(job.n_scored)], dtype=torch.float64, device=cd)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         n_scored_total = int(tot.item())
-        mine = torch.zeros((world, 5), dtype=torch.float64, device=cd)
+        mine = torch.zeros((world, 6), dtype=torch.float64, device=cd)
         mine[rank] = torch.tensor([float(np.mean(k2_ms)), float(np.median(wall)) * 1e3,
                                    float(np.median(state["xchg"])) * 1e6, executed_share_of(job),
-                                   job.scorer.sustained_clock_ghz()], dtype=torch.float64)
+                                   job.scorer.sustained_clock_ghz(), float(len(job.lin))], dtype=torch.float64)
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)
         tab = mine.cpu().numpy()
         # executed_share differs per rank: every block of rows spans another velocity range, so its shared-prefix tree
         # saves another share of the steps — K2 time per rank follows it (read the imbalance here, not as "efficiency")
         per_rank = {"social_kernel_ms": tab[:, 0].tolist(), "median_step_ms": tab[:, 1].tolist(),
                     "exchange_us": tab[:, 2].tolist(), "executed_share": tab[:, 3].tolist(),
-                    "sustained_clock_ghz": tab[:, 4].tolist()}
+                    "sustained_clock_ghz": tab[:, 4].tolist(), "rows": [int(v) for v in tab[:, 5]]}
         win_rank, win_key = state["win"]
     else:
         n_scored_total = job.n_scored
@@ -474,8 +475,9 @@ def main():
             "timed_call": ("sfw_grid_launch + selection fetch only (--resident)" if args.resident else
                            "blocking sfw_grid_stage + sfw_grid_launch + sfw_grid_fetch incl. the 8*T-byte cost vector "
                            "(= sfw_score_grid); world state resident"),
-            "parallelism": (f"linvel rows sharded over {world} GPU(s): one {w.nv // world}-row block per rank, "
-                            "all-reduce(min) of the [N,4] f64 selection-key table per step") if world > 1 else "single GPU",
+            "parallelism": (f"{w.nv} linvel rows sharded over {world} GPU(s): contiguous blocks of equal planned work (about "
+                            f"{w.nv // world} rows per rank, per_rank.rows), all-reduce(min) of the [N,4] f64 selection-key table "
+                            "per step") if world > 1 else "single GPU",
         },
         "kernel_ms": {"rollout": res["k1_ms"], "social": res["k2_ms"], "argmin": res["k3_ms"],
                       "launch_total": res["launch_ms"]},

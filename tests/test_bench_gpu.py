@@ -69,7 +69,8 @@ def test_two_ranks_on_one_gpu_over_gloo():
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d2 = _last_json(r.stdout)
-    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["config"]["samples_per_gpu"] == 65536
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and sum(d2["per_rank"]["rows"]) == 512
+    assert abs(d2["config"]["samples_per_gpu"] - 65536) < 0.15 * 65536  # blocks of equal planned work, not of equal row counts
     assert len(d2["per_rank"]["social_kernel_ms"]) == 2 and min(d2["per_rank"]["exchange_us"]) > 0
     assert len(d2["per_rank"]["executed_share"]) == 2 and all(0 < v <= 1 for v in d2["per_rank"]["executed_share"])
     # rank 0 alone through sfw_multi_score_grid (one process, two ranks): printed next to the torchrun numbers
