@@ -323,6 +323,20 @@ def test_cfg4_full_size_properties(hip_mod):
     _full_size_properties(hip_mod, syn.WORKLOADS["cfg4"], [0, 511, 1023])
 
 
+def test_cfg4_spec_crowd_full_size(oracle_mod, hip_mod):
+    """cfg4 with SURVEY §8d's crowd as specified (200 pedestrians from 0.8 m, not the 2.1 m of the benched variant): at
+    full size every sample ends in a pedestrian contact or on the costmap — the properties hold, the selection is "none",
+    and a sub-grid spread over the whole grid matches the oracle sample by sample."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg4"], people_r_in=0.8)
+    scene, costs, best = _full_size_properties(hip_mod, w, [0, 511, 1023])
+    assert best["index"] == -1 and best["n_valid"] == 0 and set(np.unique(costs).tolist()) <= {-1.0, -2.0}
+    rows, cols = np.arange(0, 1024, 128), np.arange(0, 1024, 128)
+    o = oracle_mod.OracleScorer(_params_for(w))
+    o.load_scene(scene)
+    oc, _ = o.score_grid(scene.robot_state, scene.linvels[rows], scene.angvels[cols], scene.goal_args, n_threads=64)
+    assert np.array_equal(oc, costs.reshape(1024, 1024)[np.ix_(rows, cols)].ravel())
+
+
 def test_multi_gpu_key_and_index_base(hip_mod):
     """Row shards scored with index_base reproduce the single-launch selection
     through the 4-double exchange key (what each rank contributes to the all-reduce)."""
