@@ -645,6 +645,9 @@ int plan_tables(sfw_handle h) {
   int64_t chunk = static_cast<int64_t>(
       h->table_budget_bytes / ((sizeof(sfw_robot_step) + sizeof(sfw_pose_frame) + sizeof(int16_t)) * S));
   if (chunk < 1024) chunk = 1024;
+  // the register-form K2 addresses a sample's record inside a table row by a 32-bit byte offset
+  const int64_t row_limit = static_cast<int64_t>((uint64_t(1) << 32) / sizeof(sfw_robot_step)) - 1;
+  if (chunk > row_limit) chunk = row_limit;
   if (chunk > T) chunk = T;
   SFW_HIP(h, h->rstep.reserve(static_cast<size_t>(chunk) * S));
   SFW_HIP(h, h->frame.reserve(static_cast<size_t>(chunk) * S));
