@@ -212,6 +212,9 @@ bool all_finite(const double *v, size_t n) {
   return true;
 }
 
+// the register-form K2 addresses a sample's record inside a row of the K1->K2 table by a 32-bit byte offset
+constexpr int64_t kRowLimit = static_cast<int64_t>((uint64_t(1) << 32) / sizeof(sfw_robot_step)) - 1;
+
 int num_steps_of(const sfw_params &p) {
   int n = static_cast<int>(p.sim_time / p.sim_granularity + 0.5);  // ref :519
   return n == 0 ? 1 : n;                                           // ref :523-525
@@ -645,9 +648,7 @@ int plan_tables(sfw_handle h) {
   int64_t chunk = static_cast<int64_t>(
       h->table_budget_bytes / ((sizeof(sfw_robot_step) + sizeof(sfw_pose_frame) + sizeof(int16_t)) * S));
   if (chunk < 1024) chunk = 1024;
-  // the register-form K2 addresses a sample's record inside a table row by a 32-bit byte offset
-  const int64_t row_limit = static_cast<int64_t>((uint64_t(1) << 32) / sizeof(sfw_robot_step)) - 1;
-  if (chunk > row_limit) chunk = row_limit;
+  if (chunk > kRowLimit) chunk = kRowLimit;
   if (chunk > T) chunk = T;
   SFW_HIP(h, h->rstep.reserve(static_cast<size_t>(chunk) * S));
   SFW_HIP(h, h->frame.reserve(static_cast<size_t>(chunk) * S));
@@ -768,6 +769,7 @@ int launch_common(sfw_handle h) {
   }
   const int S = num_steps_of(h->params);
   int64_t chunk = static_cast<int64_t>(std::min(h->rstep.cap, std::min(h->frame.cap, h->fcode.cap)) / S);
+  if (chunk > kRowLimit) chunk = kRowLimit;
   if (chunk > T) chunk = T;
   if (chunk < 1) return fail(h, SFW_ERR_STATE, "robot-step table too small");
   if (int e = check_lds(h, chunk)) return e;
