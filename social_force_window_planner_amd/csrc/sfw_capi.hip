@@ -141,6 +141,9 @@ struct sfw_planner_s {
   int k2_form = SFW_K2_AUTO;     // sfw_set_k2_form / SFW_FORCE_FLAT
   // sfw_set_points_capture: a grid small enough for the fused K1 (a control cycle's samples) leaves its Trajectory points,
   // point counts and contact steps during the scoring launch itself, in one buffer -> the dump is one D2H copy
+  // K1a of a single-chunk grid is enqueued by the STAGE, before the shared-prefix planning (25..45 us of host work that
+  // the pose rollout does not depend on): early_poses says the staged grid's robot-step table is already in the stream
+  bool early_poses = false;
   bool capture_points = false, captured = false;
   dev_buf<char> cap;             // points (24 S T bytes) | n_points (4 T) | contact steps (4 T)
   pinned_buf pin_cap;
@@ -642,9 +645,10 @@ void rest_forces(const sfw_params &p, const std::vector<std::pair<int32_t, int32
 // Run by every stage, and again by a launch when sfw_set_params came in between (the reference re-reads
 // its parameters every cycle, :125): a plan made for another dt would merge samples whose robot
 // trajectories now differ.
-int plan_tables(sfw_handle h) {
+int plan_tables(sfw_handle h, bool may_start_poses = false) {
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
   const int S = num_steps_of(h->params);
+  h->early_poses = false;
   int64_t chunk = static_cast<int64_t>(
       h->table_budget_bytes / ((sizeof(sfw_robot_step) + sizeof(sfw_pose_frame) + sizeof(int16_t)) * S));
   if (chunk < 1024) chunk = 1024;
@@ -653,6 +657,16 @@ int plan_tables(sfw_handle h) {
   SFW_HIP(h, h->rstep.reserve(static_cast<size_t>(chunk) * S));
   SFW_HIP(h, h->frame.reserve(static_cast<size_t>(chunk) * S));
   SFW_HIP(h, h->fcode.reserve(static_cast<size_t>(chunk) * S));
+  if (may_start_poses && chunk >= T) {
+    // the robot's poses depend on the sample vectors alone: the GPU rolls them out while the host plans the prefix tree
+    sfw_launch L;
+    fill_launch(h, L, 0, T, T);
+    if (!sfw_rollout_is_fused(L)) {  // (the fused small-grid K1 is one launch with the costmap part, and may capture points)
+      if (h->timing) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
+      SFW_HIP(h, sfw_launch_rollout_poses(L, h->stream));
+      h->early_poses = true;
+    }
+  }
   if (int e = plan_prefix(h, chunk, S)) return e;
   h->plan_epoch = h->params_epoch;
   return SFW_OK;
@@ -667,7 +681,8 @@ int check_lds(sfw_handle h, int64_t items) {
 }
 
 int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int32_t nv, const double *ang,
-                 int32_t nw, const sfw_goal_args *args, double vy_samp, int skip_zero, int64_t index_base) {
+                 int32_t nw, const sfw_goal_args *args, double vy_samp, int skip_zero, int64_t index_base,
+                 bool grid = false) {
   if (!h) return SFW_ERR_INVALID_ARG;
   if (!rs || !lin || !ang || !args || nv <= 0 || nw <= 0)
     return fail(h, SFW_ERR_INVALID_ARG, "grid_stage: null pointer or non-positive sample count");
@@ -743,7 +758,7 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   SFW_HIP(h, h->costs.reserve(T + (sizeof(sfw_sel) + sizeof(double) - 1) / sizeof(double)));
   h->d_sel = reinterpret_cast<sfw_sel *>(h->costs.p + T);
   SFW_HIP(h, h->partials.reserve(sfw_argmin_partials(T)));
-  if (int e = plan_tables(h)) return e;
+  if (int e = plan_tables(h, grid)) return e;
   h->staged = true;
   h->launched = false;
   return SFW_OK;
@@ -756,7 +771,7 @@ int launch_common(sfw_handle h) {
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
   // sfw_set_params since the stage: tables and shared-prefix plan are redone for the live parameters
   if (h->plan_epoch != h->params_epoch) {
-    if (int e = plan_tables(h)) return e;
+    if (int e = plan_tables(h)) return e;  // (also drops the poses the stage started: they were rolled out under the old parameters)
     if (h->d_agent_rest && !h->st_rest_pairs.empty()) {  // the relative-rest terms depend on the sfm parameters too
       const size_t bytes = sizeof(double) * 2 * static_cast<size_t>(h->st_A);
       SFW_HIP(h, h->pin_cls.wait());
@@ -777,10 +792,12 @@ int launch_common(sfw_handle h) {
   const bool prefix = !h->prefix_steps.empty() && h->prefix_S == S && h->prefix_chunk <= chunk;
   if (prefix) chunk = h->prefix_chunk;
   const bool timing = h->timing;
+  const bool poses_done = h->early_poses && chunk >= T;  // the stage enqueued K1a of this (single-chunk) grid already
+  h->early_poses = false;                                 // ... once: a second launch of the same stage rolls out again
   if (timing) {
     SFW_HIP(h, h->clock.reserve(4));
     SFW_HIP(h, hipMemsetAsync(h->clock.p, 0, 4 * sizeof(unsigned long long), h->stream));
-    SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
+    if (!poses_done) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
   }
   const bool single = chunk >= T;
   h->n_chunks = static_cast<int>((T + chunk - 1) / chunk);
@@ -824,7 +841,7 @@ int launch_common(sfw_handle h) {
     if (prefix) {
       // K1a -> { K2 prefix phase on the main stream  ||  K1b + K1c on the side stream } -> K2 suffix phase.
       // The prefix phase needs the robot-step table only and under-fills the GPU (one item per class).
-      SFW_HIP(h, sfw_launch_rollout_poses(L, h->stream));
+      if (!poses_done) SFW_HIP(h, sfw_launch_rollout_poses(L, h->stream));
       SFW_HIP(h, hipEventRecord(h->ev_poses, h->stream));
       SFW_HIP(h, hipStreamWaitEvent(h->side, h->ev_poses, 0));
       SFW_HIP(h, sfw_launch_rollout_costmap(L, h->side));
@@ -866,7 +883,8 @@ int launch_common(sfw_handle h) {
       L.in_dead = h->cls_dead[(n_lv - 1) & 1].p;
       SFW_HIP(h, sfw_launch_social(L, h->stream));
     } else {
-      SFW_HIP(h, sfw_launch_rollout(L, h->stream));
+      if (!poses_done) SFW_HIP(h, sfw_launch_rollout_poses(L, h->stream));
+      SFW_HIP(h, sfw_launch_rollout_costmap(L, h->stream));
       if (timing) SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
       SFW_HIP(h, sfw_launch_social(L, h->stream));
     }
@@ -1170,7 +1188,7 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
 
 int sfw_grid_stage(sfw_handle h, const sfw_robot_state *rs, const double *linvels, int32_t nv,
                    const double *angvels, int32_t nw, const sfw_goal_args *args, int64_t index_base) {
-  return stage_common(h, rs, linvels, nv, angvels, nw, args, 0.0, 1, index_base);
+  return stage_common(h, rs, linvels, nv, angvels, nw, args, 0.0, 1, index_base, true);
 }
 
 int sfw_grid_launch(sfw_handle h) { return launch_common(h); }
