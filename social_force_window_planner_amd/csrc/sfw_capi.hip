@@ -145,6 +145,7 @@ struct sfw_planner_s {
   // the pose rollout does not depend on): early_poses says the staged grid's robot-step table is already in the stream
   bool early_poses = false;
   bool capture_points = false, captured = false;
+  int cap_S = 0;                 // step count the capturing launch ran with (the dump's layout)
   dev_buf<char> cap;             // points (24 S T bytes) | n_points (4 T) | contact steps (4 T)
   pinned_buf pin_cap;
 
@@ -588,7 +589,7 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
 // standing person) and motion exactly along the connecting line (two people on one grid-aligned line walking towards
 // or away from each other).  There the model's interaction angle theta is mathematically 0 or +-pi and its angular
 // term -sign(theta) exp(-d/B - (n B theta)^2) leftNormal(Ihat) is discontinuous.  The kernels take sign(theta) from
-// w x diff, exactly 0 here, so their angular term vanishes.  lightsfm instead forms theta as the difference of two
+// w x diff, exactly 0 here: the sign of a zero (their exact zero in the SFW_SIGN_OF_ZERO=0 build).  lightsfm instead forms theta as the difference of two
 // atan2 — of vectors equal up to rounding when I = lambda w + dhat points along dhat (sign(theta) = -1, 0 or +1 by the
 // rounding of the HOST's libm: a full-magnitude lateral force on an ordinary scene), of opposite vectors when the pair
 // separates faster than 1/lambda (theta = +-pi by the sign of a zero).  Such a configuration can only come from the state
@@ -821,6 +822,7 @@ int launch_common(sfw_handle h) {
       cap_n = cap_pts + pts_bytes;
       cap_coll = cap_n + 4 * static_cast<size_t>(T);
       h->captured = true;
+      h->cap_S = S;
     }
   }
   int c = 0;
@@ -1397,7 +1399,7 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
   SFW_HIP(h, hipSetDevice(h->device));
   const int S = num_steps_of(h->params);
   const size_t n = static_cast<size_t>(count);
-  if (h->launched && h->captured) {
+  if (h->launched && h->captured && h->cap_S == S) {  // (sfw_set_params since the launch changed the step count: re-run below)
     // the scoring launch left everything (sfw_set_points_capture): ONE copy of points | counts | contact steps, no kernel
     const size_t pts_bytes = sizeof(double) * 3 * static_cast<size_t>(S) * static_cast<size_t>(T), total = pts_bytes + 8 * static_cast<size_t>(T);
     SFW_HIP(h, h->pin_cap.reserve(total));
