@@ -1753,8 +1753,17 @@ int sfw_multi_set_footprint(sfw_multi_handle m, const double *xy, int32_t K) {
 }
 int sfw_multi_set_agents(sfw_multi_handle m, const sfw_agent *agents, int32_t A, const double *obstacles_xy, int32_t O) {
   if (!m) return SFW_ERR_INVALID_ARG;
-  for (int r = 0; r < m->R; ++r)
-    if (int e = sfw_set_agents(m->h[static_cast<size_t>(r)], agents, A, obstacles_xy, O)) return mrank_fail(m, r, e, "sfw_set_agents");
+  // validated, packed and scanned for w x diff == 0 pairs ONCE (the scan is all pairs); the other ranks take rank 0's
+  // host-side copy — the upload happens per rank with its next stage
+  sfw_handle h0 = m->h[0];
+  if (int e = sfw_set_agents(h0, agents, A, obstacles_xy, O)) return mrank_fail(m, 0, e, "sfw_set_agents");
+  for (int r = 1; r < m->R; ++r) {
+    sfw_handle h = m->h[static_cast<size_t>(r)];
+    h->h_agents = h0->h_agents;
+    h->ao_vel = h0->ao_vel; h->ao_cst = h0->ao_cst; h->ao_obs = h0->ao_obs; h->ao_grp = h0->ao_grp; h->ao_off = h0->ao_off; h->ao_mem = h0->ao_mem;
+    h->A = h0->A; h->O = h0->O; h->NG = h0->NG; h->n_grp_mem = h0->n_grp_mem;
+    h->rest_pairs = h0->rest_pairs;
+  }
   return SFW_OK;
 }
 
