@@ -60,6 +60,9 @@ def parse_args():
                     help="collective backend for N > 1 (gloo: CPU tensors; lets several ranks share one GPU in tests)")
     ap.add_argument("--inproc-workload", default="cfg5",
                     help="N > 1: the workload rank 0 also scores through sfw_multi_score_grid over all N devices (extra.inproc_multi_*)")
+    ap.add_argument("--inproc-child", default=None, help=argparse.SUPPRESS)  # workload:devices:exchange:steps:warmup
+    ap.add_argument("--inproc-timeout", type=float, default=420.0,
+                    help="N > 1: wall-clock limit of each one-process multi-device measurement (run in a child process)")
     ap.add_argument("--grid", default=None, help="override the sample grid, e.g. 512x512 (experiments only)")
     ap.add_argument("--verify", action="store_true", help="check the GPU result against the oracle on a sample subset")
     ap.add_argument("--resident", action="store_true",
@@ -304,6 +307,29 @@ def inproc_multi(workload_name, precision, devices, exchange, steps, warmup):
         m.close()
 
 
+def inproc_multi_guarded(workload_name, precision, devices, exchange, steps, warmup, limit_s):
+    """inproc_multi in a CHILD process under a wall-clock limit: the RCCL leg (ncclCommInitAll over every device of the
+    node while each device also carries a torchrun rank's context) has only ever run where a node was available — a hang
+    there must cost this entry, not the bench line.  The child is this file with --inproc-child; it needs no torch."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                        "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "HIP_VISIBLE_DEVICES_RANK")}
+    spec = f"{workload_name}:{','.join(str(d) for d in devices)}:{exchange}:{steps}:{warmup}"
+    cmd = [sys.executable, os.path.abspath(__file__), "--inproc-child", spec, "--precision", precision]
+    if GRID_OVERRIDE:
+        cmd += ["--grid", GRID_OVERRIDE]
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {limit_s:.0f} s (child stopped)"}
+    for line in reversed(out.stdout.splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"error": f"child exit {out.returncode}: {out.stderr.strip()[-400:]}"}
+
+
 def host_wait(dist, rank, key):
     """Rank 0 releases the others through the process group's store (CPU-side wait); a barrier if there is no store."""
     try:
@@ -422,6 +448,14 @@ def main():
     args = parse_args()
     global GRID_OVERRIDE
     GRID_OVERRIDE = args.grid
+    if args.inproc_child:
+        name, devs, xchg, st, wu = args.inproc_child.split(":")
+        try:
+            res = inproc_multi(name, args.precision, [int(d) for d in devs.split(",")], int(xchg), int(st), int(wu))
+        except Exception as e:
+            res = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -529,10 +563,9 @@ def main():
 
             devs, xchg = (list(range(world)), SFW_MULTI_RCCL) if args.backend == "nccl" else ([local_rank] * world, SFW_MULTI_HOST_REDUCE)
             for name, st, wu in ((args.inproc_workload, 3, 1), (args.workload, 20, 3)):
-                try:
-                    extra["inproc_multi_" + name] = inproc_multi(name, args.precision, devs, xchg, st, wu)
-                except Exception as e:  # a broken RCCL install must not take the headline line down
-                    extra["inproc_multi_" + name] = {"error": repr(e)}
+                # child process + wall-clock limit: neither a broken RCCL install nor a hang takes the bench line down
+                extra["inproc_multi_" + name] = inproc_multi_guarded(name, args.precision, devs, xchg, st, wu,
+                                                                    args.inproc_timeout)
         # the others wait on the HOST (a key of the rendezvous store): a collective would park a spinning RCCL kernel on
         # every device rank 0 is about to use
         host_wait(dist, rank, "sfw_inproc_multi_done")

@@ -87,6 +87,22 @@ def test_two_ranks_on_one_gpu_over_gloo():
     assert d2["global_cmd_vel"]["cost"] == d1["cmd_vel"]["cost"]
 
 
+@pytest.mark.gpu
+def test_a_stuck_one_process_leg_costs_its_entry_not_the_line():
+    """The one-process multi-device legs at N > 1 run in a child under a wall-clock limit (bench.inproc_multi_guarded): with
+    a limit no child can meet, the entries carry an error and the headline line is still printed."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo",
+           "--no-cpu-baseline", "--extras", "inproc_multi", "--inproc-workload", "cfg2", "--inproc-timeout", "0.01"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "no result within" in d["extra"]["inproc_multi_cfg2"]["error"]
+    assert "no result within" in d["extra"]["inproc_multi_target"]["error"]
+
+
+
 def test_exchange_over_rccl_single_rank():
     """The all-reduce(min) exchange on the real backend (nccl == RCCL on ROCm) with
     device tensors; a 1-rank group is all a 1-GPU box can host."""
