@@ -672,14 +672,24 @@ __device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const age
 // the allocation.
 struct lds_layout {
   double *px, *py, *vx, *vy, *fjx, *fjy, *fcx, *fcy;
-  double2 *goal, *obs, *gcen;
+  double2 *obs, *gcen;
   sfw_robot_step *rsb;  // robot records: one per sample of the wave (register form), two (flat form: this step's
                         // and the prefetched next step's)
-  double *gr, *dv, *rad, *swp;
+  sfw_agent_const *ac;  // the per-agent launch constants as they sit in global memory (48 B records: one address
+                        // register per agent reaches every field through the DS offset field)
+  double *swp;
   double2 *opart;       // flat form with laser points: the 64 lanes' partial obstacle sums of one pass
   double *wr;           // flat form with laser points: the robot's social-work term waiting for its obstacle part
-  int *id, *hasgoal, *dead, *grp, *goff, *gmem;
+  int *hasgoal, *dead, *grp, *goff, *gmem;
+  int hg_stride;        // ints between two slots' hasgoal words (see hg())
   size_t bytes;
+  // Register form (with_frc = false): everything a slot reads and writes every step sits at a COMPILE-TIME distance from
+  // its px word — the six state planes, then a plane of 8-byte cells {hasgoal, Wp switch} and the social-work plane, then
+  // the samples' contact flags and robot records — so one address register (8 * slot) and one (4 * sample) serve the
+  // whole per-agent pass; only the constants (ac) and the arrays of the laser-point / group passes have run-time bases.
+  // Round 2's layout had eight run-time array bases, i.e. eight per-lane address registers held across the rollout, four
+  // of which the allocator spilled to scratch and reloaded one after the other in every step.
+  static constexpr int REG_DEAD_CAP = 32;  // samples per register-form wave (plan_for)
   __host__ __device__ lds_layout(char *base, int A, int cap, int GA, int G, int O, int NG, int NM, bool consts,
                                  bool with_frc) {
     char *const base0 = base;
@@ -695,27 +705,42 @@ struct lds_layout {
     vy = reinterpret_cast<double *>(take(plane));
     fjx = reinterpret_cast<double *>(take(plane));
     fjy = reinterpret_cast<double *>(take(plane));
-    fcx = reinterpret_cast<double *>(take(with_frc ? plane : 0));  // flat kernel only
-    fcy = reinterpret_cast<double *>(take(with_frc ? plane : 0));
-    obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? O : 1)));
-    rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * (with_frc ? 2 : G)));
-    swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
-    opart = reinterpret_cast<double2 *>(take(sizeof(double2) * ((with_frc && O > 0) ? 64 : 0)));
-    wr = reinterpret_cast<double *>(take(sizeof(double) * ((with_frc && O > 0) ? 2 : 0)));
-    hasgoal = reinterpret_cast<int *>(take(sizeof(int) * GA));
-    dead = reinterpret_cast<int *>(take(sizeof(int) * G));
-    const int Ac = consts ? A : 0;
-    goal = reinterpret_cast<double2 *>(take(sizeof(double2) * Ac));
-    gr = reinterpret_cast<double *>(take(sizeof(double) * Ac));
-    dv = reinterpret_cast<double *>(take(sizeof(double) * Ac));
-    rad = reinterpret_cast<double *>(take(sizeof(double) * Ac));
-    id = reinterpret_cast<int *>(take(sizeof(int) * Ac));
-    gcen = reinterpret_cast<double2 *>(take(sizeof(double2) * (NG > 0 ? G * NG : 1)));
-    grp = reinterpret_cast<int *>(take(sizeof(int) * (NG > 0 ? A : 1)));
-    goff = reinterpret_cast<int *>(take(sizeof(int) * (NG + 1)));
-    gmem = reinterpret_cast<int *>(take(sizeof(int) * (NM > 0 ? NM : 1)));
+    if (with_frc) {  // flat kernel
+      fcx = reinterpret_cast<double *>(take(plane));
+      fcy = reinterpret_cast<double *>(take(plane));
+      obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? O : 1)));
+      rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * 2));
+      swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
+      opart = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? 64 : 0)));
+      wr = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? 2 : 0)));
+      hasgoal = reinterpret_cast<int *>(take(sizeof(int) * GA));
+      hg_stride = 1;
+      dead = reinterpret_cast<int *>(take(sizeof(int) * G));
+    } else {         // register form: fixed distances first (reg_off below restates them)
+      fcx = fcy = nullptr;
+      opart = nullptr;
+      wr = nullptr;
+      hasgoal = reinterpret_cast<int *>(take(plane));
+      hg_stride = 2;
+      swp = reinterpret_cast<double *>(take(plane));
+      dead = reinterpret_cast<int *>(take(sizeof(int) * REG_DEAD_CAP));
+      rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * G));
+      obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? O : 1)));
+    }
+    ac = reinterpret_cast<sfw_agent_const *>(take(sizeof(sfw_agent_const) * (consts ? A : 0)));
+    // group arrays only when an agent carries a group id (the GROUPS kernels): nothing reads them otherwise
+    gcen = reinterpret_cast<double2 *>(take(sizeof(double2) * (NG > 0 ? G * NG : 0)));
+    grp = reinterpret_cast<int *>(take(sizeof(int) * (NG > 0 ? A : 0)));
+    goff = reinterpret_cast<int *>(take(sizeof(int) * (NG > 0 ? NG + 1 : 0)));
+    gmem = reinterpret_cast<int *>(take(sizeof(int) * (NG > 0 && NM > 0 ? NM : 0)));
     bytes = static_cast<size_t>(base - base0);
   }
+  __device__ __forceinline__ int &hg(int sl) const { return hasgoal[sl * hg_stride]; }
+};
+// Byte offsets of the register form's fixed part from a slot's px word (CAP = 64 * NS doubles per plane).
+template <int CAP> struct reg_off {
+  static constexpr int PY = 8 * CAP, VX = 16 * CAP, VY = 24 * CAP, FJX = 32 * CAP, FJY = 40 * CAP, HG = 48 * CAP, SW = 56 * CAP,
+                       DEAD = 64 * CAP, RSB = 64 * CAP + 4 * lds_layout::REG_DEAD_CAP;
 };
 
 // Per-agent launch constants as agent_step consumes them.
@@ -723,14 +748,11 @@ struct agent_k {
   double gx, gy, gr, dv, rad;
   int id;
 };
-__device__ __forceinline__ agent_k agent_k_lds(const lds_layout &s, int i) {
-  const double2 g = s.goal[i];
-  return agent_k{g.x, g.y, s.gr[i], s.dv[i], s.rad[i], s.id[i]};
-}
-__device__ __forceinline__ agent_k agent_k_global(const sfw_agent_const *agent_c, int i) {
-  const sfw_agent_const c = agent_c[i];
+__device__ __forceinline__ agent_k agent_k_of(const sfw_agent_const &c) {
   return agent_k{c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity, c.radius, c.id};
 }
+__device__ __forceinline__ agent_k agent_k_lds(const lds_layout &s, int i) { return agent_k_of(s.ac[i]); }
+__device__ __forceinline__ agent_k agent_k_global(const sfw_agent_const *agent_c, int i) { return agent_k_of(agent_c[i]); }
 
 // lightsfm computeGroupForce (non-_PAPER_VERSION_ branch)
 // for agent i of sample g at position (px,py): gaze + coherence + repulsion.
@@ -743,6 +765,7 @@ __device__ __forceinline__ agent_k agent_k_global(const sfw_agent_const *agent_c
 template <typename R>
 __device__ double2 group_force(const sfm_consts<R> &k, const agent_consts &c, const lds_layout &s, int NG, int g, int A,
                                int i, int sl, double px, double py) {
+  const sfw_agent_const ci = s.ac[i];
   const int q = s.grp[i];
   if (q < 0) return double2{0.0, 0.0};
   const int m0 = s.goff[q], m1 = s.goff[q + 1];
@@ -751,11 +774,10 @@ __device__ double2 group_force(const sfm_consts<R> &k, const agent_consts &c, co
   const double2 csum = s.gcen[g * NG + q];
   const double cx = csum.x * inv_n, cy = csum.y * inv_n;
   // desired direction at this state (zero when the agent has no goal to walk to)
-  const double2 gl = s.goal[i];
-  const double ex = gl.x - px, ey = gl.y - py;
+  const double ex = ci.goal_x - px, ey = ci.goal_y - py;
   double inv_en, en;
   sfwm::rsqrt_sqrt(fmax(fma(ex, ex, ey * ey), 1e-300), inv_en, en);
-  const bool has_dir = s.hasgoal[sl] && en > s.gr[i];
+  const bool has_dir = s.hg(sl) && en > ci.goal_radius;
   const double ddx = has_dir ? ex * inv_en : 0.0, ddy = has_dir ? ey * inv_en : 0.0;
   double fx = 0.0, fy = 0.0;
   {  // gaze: pulls along the desired direction when the rest of the group is behind
@@ -777,11 +799,11 @@ __device__ double2 group_force(const sfm_consts<R> &k, const agent_consts &c, co
     fy = fma(ry, soft, fy);
   }
   double rx = 0.0, ry = 0.0;  // repulsion between overlapping members
-  const double ra = s.rad[i];
+  const double ra = ci.radius;
   for (int m = m0; m < m1; ++m) {
     const int b = s.gmem[m];
     if (b == i) continue;
-    const double dx = px - s.px[g * A + b], dy = py - s.py[g * A + b], rr = ra + s.rad[b];
+    const double dx = px - s.px[g * A + b], dy = py - s.py[g * A + b], rr = ra + s.ac[b].radius;
     if (fma(dx, dx, dy * dy) < rr * rr) { rx += dx; ry += dy; }
   }
   fx = fma(rx, c.f_repulsion, fx);
@@ -808,18 +830,33 @@ template <typename R, bool PIN_ALL> __device__ __forceinline__ sfm_consts<R> mak
   return k;
 }
 
+// The same from the late-read kernel arguments (see late_args): for a kernel that builds the constants once per step.
+template <typename R, bool PIN_ALL> __device__ __forceinline__ sfm_consts<R> make_consts(late_launch La) {
+  constexpr bool F32 = sizeof(R) == 4;
+  sfm_consts<R> k;
+  const R lambda = F32 ? R(La->k.f.lambda) : R(La->k.d.lambda), nig = F32 ? R(La->k.f.neg_inv_gamma) : R(La->k.d.neg_inv_gamma);
+  const R lfs = F32 ? R(La->k.f.ln_f_social) : R(La->k.d.ln_f_social), cv = F32 ? R(La->k.f.c_vel) : R(La->k.d.c_vel);
+  const R ca = F32 ? R(La->k.f.c_ang) : R(La->k.d.c_ang);
+  k.lambda = sfwm::vgpr_const(lambda);
+  k.neg_inv_gamma = sfwm::vgpr_const(nig);
+  k.ln_f_social = PIN_ALL ? sfwm::vgpr_const(lfs) : lfs;
+  k.c_vel = sfwm::vgpr_const(cv);
+  k.c_ang = PIN_ALL ? sfwm::vgpr_const(ca) : ca;
+  return k;
+}
+
 // One agent slot after the pair pass of a step: integrate the person (the robot's
 // overwrite is the caller's), contact test, social-work terms, next step's
 // desired+obstacle force.  F = total force on the agent at the pre-step state
 // (for the robot: its social force only).  Returns this slot's social work.
 // The laser-point term is the caller's: `work` lacks the robot's obstacle part and (nfx, nfy) a person's obstacle force.
 template <typename R>
-__device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const agent_consts &c, const lds_layout &s,
-                                             const sfw_robot_step &rs, const agent_k &ak, int step, int i, int g,
-                                             int sl, double &px, double &py, double &vx, double &vy, double Fx,
-                                             double Fy, double &nfx, double &nfy) {
+__device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const agent_consts &c, const sfw_robot_step &rs,
+                                             const agent_k &ak, bool robot, bool wp_on, int &hg, bool &contact,
+                                             double &px, double &py, double &vx, double &vy, double Fx, double Fy,
+                                             double &nfx, double &nfy) {
   double work = 0.0;
-  const bool robot = (i == 0);
+  contact = false;
   nfx = 0.0;
   nfy = 0.0;
   if (robot) {
@@ -837,17 +874,15 @@ __device__ __forceinline__ double agent_step(const sfm_consts<R> &k, const agent
     }
     px = fma(vx, c.dt, px);
     py = fma(vy, c.dt, py);
-    int hg = s.hasgoal[sl];
     if (hg) {
       const double ex = ak.gx - px, ey = ak.gy - py;
       if (fast_norm(ex, ey) <= ak.gr) hg = 0;  // goal reached: pop
-      s.hasgoal[sl] = hg;
     }
     // dynamic collision with the robot's post-step pose (ref :613-627)
     const double cx = rs.x - px, cy = rs.y - py;
-    if (cx * cx + cy * cy <= c.rr) s.dead[g] = 2 + step;  // >= 2: rejected by contact at `step`
+    contact = cx * cx + cy * cy <= c.rr;  // the caller marks the sample rejected at this step
     // Wp (ref :692-699): force the post-step robot alone exerts on this person
-    if (ak.id != c.robot_id) {
+    if (wp_on) {  // a person whose id is not the robot's (ref :692)
       R qn, unused;
       pair_force_state<R, true>(k, px, py, vx, vy, rs.x, rs.y, rs.vx, rs.vy, qn, unused);
       work = static_cast<double>(qn);
@@ -896,12 +931,7 @@ __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout
   if (static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char *)(s.px))) != 0u) __builtin_trap();
   if constexpr (CONSTS) {
     for (int i = lane; i < A; i += WAVE) {
-      const sfw_agent_const c = L.agent_c[i];
-      s.goal[i] = double2{c.goal_x, c.goal_y};
-      s.gr[i] = c.goal_radius;
-      s.dv[i] = c.desired_velocity;
-      s.rad[i] = c.radius;
-      s.id[i] = c.id;
+      s.ac[i] = L.agent_c[i];
     }
   }
   for (int o = lane; o < O; o += WAVE) s.obs[o] = double2{L.obstacles[2 * o], L.obstacles[2 * o + 1]};
@@ -1001,6 +1031,16 @@ __device__ __forceinline__ void lds_pair_state(uint32_t io, uint32_t jo, double 
       : "memory");
 }
 
+// Two ds_add_f64 (no return) into planes FX / FY of the slot at byte offset `o`, written as asm.  As compiler-generated
+// atomics they are DS accesses the wait-count pass has to order against the LDS-direct load of the step's robot records
+// (global_load_lds writes LDS behind the compiler's back): it put an s_waitcnt vmcnt(0) in front of them, i.e. the first
+// row of every step waited for the load that was issued to be in flight during the whole pair pass.  The LDS executes a
+// wave's operations in issue order, so the agent pass reads the sums without further ado (its first s_waitcnt lgkmcnt
+// covers them: the counter is decremented in order).
+template <int FX, int FY> __device__ __forceinline__ void lds_add_pair(uint32_t o, double x, double y) {
+  asm volatile("ds_add_f64 %0, %1 offset:%3\n\tds_add_f64 %0, %2 offset:%4" : : "v"(o), "v"(x), "v"(y), "n"(FX), "n"(FY) : "memory");
+}
+
 // ---------------------------------------------------------------------------
 // K2, register-resident form: every lane owns NS agent slots (slot = r*64+lane,
 // slot -> (sample g, agent i)) whose force accumulator and social-work sum stay in
@@ -1014,7 +1054,8 @@ template <typename R, int NS, bool GROUPS>
 __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social_kernel(const sfw_launch L, const int G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CAP = WAVE * NS;  // GA <= CAP: state planes at compile-time distances
-  constexpr int PY = 8 * CAP, VX = 16 * CAP, VY = 24 * CAP, FJX = 32 * CAP, FJY = 40 * CAP;  // byte offsets from px[]
+  using off = reg_off<CAP>;       // byte offsets from a slot's px word
+  constexpr int PY = off::PY, VX = off::VX, VY = off::VY, FJX = off::FJX, FJY = off::FJY;
   const int lane = threadIdx.x;
   const int A = L.A, O = L.O;
   const int GA = G * A;
@@ -1024,7 +1065,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   const int64_t remain = item_count(L) - first_local;
   const int Gn = remain < G ? static_cast<int>(remain) : G;
   const int step_begin = L.step_begin, step_end = L.step_end;
-  const sfm_consts<R> k = make_consts<R, false>(L);
+  const sfm_consts<R> k0 = make_consts<R, false>(L);  // the prologue's; every step builds its own (below)
   constexpr bool F32 = sizeof(R) == 4;
   if (!stage_wave<GROUPS, true>(L, s, lane, G, Gn, first_local)) {
     // nothing to integrate; items that inherit a contact still pass the verdict on
@@ -1035,12 +1076,17 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   clock_probe(0);
 
   // ---- this lane's slots --------------------------------------------------
+  // A slot is addressed through three registers for the whole rollout: io = 8 * slot (the planes, its {hasgoal, Wp}
+  // cell and its social-work word at the fixed distances of reg_off), ci = the LDS address of its agent's constants,
+  // g4 = 4 * sample (contact flag at off::DEAD, robot record at off::RSB + 8 * g4).
   int sl_[NS], g_[NS], i_[NS];
+  uint32_t io_[NS], ci_[NS], g4_[NS];
   bool ok_[NS];
   // Registers hold only the force accumulator and the social-work sum of a slot; position and
   // velocity are re-read from LDS where needed (LDS has the headroom): with them in VGPRs the
   // NS = 1 kernel needs 87 registers, i.e. scratch spills under the 80 that six waves per SIMD allow.
   double fx[NS], fy[NS], sw[NS];
+  const uint32_t ac_off = static_cast<uint32_t>(reinterpret_cast<char *>(s.ac) - smem);
   {
     const agent_consts c0 = load_agent_consts(late_args(), F32);
 #pragma unroll
@@ -1051,8 +1097,13 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
       g_[r] = (G == 1) ? 0 : slc / A;
       i_[r] = slc - g_[r] * A;
       sl_[r] = slc;
+      io_[r] = 8u * static_cast<uint32_t>(slc);
+      ci_[r] = ac_off + static_cast<uint32_t>(sizeof(sfw_agent_const)) * static_cast<uint32_t>(i_[r]);
+      g4_[r] = 4u * static_cast<uint32_t>(g_[r]);
       const int i = i_[r];
       fx[r] = fy[r] = sw[r] = 0.0;
+      // the slot's Wp switch: a person whose id is not the robot's receives the robot-on-person term (ref :692)
+      const int wp_on = (i != 0 && s.ac[i].id != c0.robot_id) ? 1 : 0;
       if (L.resume) {  // resume from the record of the item's (parent) class
         if (ok_[r] && g_[r] < Gn) {
           const sfw_cls_agent c = L.in_state[source_class_of_item(L, first_local + g_[r]) * A + i];
@@ -1061,13 +1112,13 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
           s.vx[sl] = c.vx;
           s.vy[sl] = c.vy;
           s.fjx[sl] = s.fjy[sl] = 0.0;
-          s.hasgoal[sl] = c.hasgoal;
+          lds_at<int2>(smem, io_[r] + off::HG) = int2{c.hasgoal, wp_on};
           fx[r] = c.fx;
           fy[r] = c.fy;
           sw[r] = c.sw;
         } else if (ok_[r]) {
           s.px[sl] = s.py[sl] = s.vx[sl] = s.vy[sl] = s.fjx[sl] = s.fjy[sl] = 0.0;
-          s.hasgoal[sl] = 0;
+          lds_at<int2>(smem, io_[r] + off::HG) = int2{0, wp_on};
         }
         continue;
       }
@@ -1080,13 +1131,13 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         s.vx[sl] = vx;
         s.vy[sl] = vy;
         s.fjx[sl] = s.fjy[sl] = 0.0;
-        s.hasgoal[sl] = hg;
+        lds_at<int2>(smem, io_[r] + off::HG) = int2{hg, wp_on};
         if (i != 0) {
-          const double2 gl = s.goal[i];
-          desired_force(c0, px, py, vx, vy, hg != 0, gl.x, gl.y, s.gr[i], s.dv[i], fx[r], fy[r]);
+          const agent_k ak = agent_k_lds(s, i);
+          desired_force(c0, px, py, vx, vy, hg != 0, ak.gx, ak.gy, ak.gr, ak.dv, fx[r], fy[r]);
           if (O > 0) {
             double ox, oy;
-            obstacle_force<R>(k, c0, s.obs, px, py, s.rad[i], ox, oy);
+            obstacle_force<R>(k0, c0, s.obs, px, py, ak.rad, ox, oy);
             fx[r] += ox;
             fy[r] += oy;
           }
@@ -1101,7 +1152,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   __syncthreads();
   // Group forces belong to the force at the CURRENT state, so they are added to
   // the starting force after every state update (and once here for step 0).
-  auto add_group_forces = [&](const agent_consts &c) {
+  auto add_group_forces = [&](const sfm_consts<R> &k, const agent_consts &c) {
     for (int q = lane; q < G * NG; q += WAVE) s.gcen[q] = double2{0.0, 0.0};
     __syncthreads();
 #pragma unroll
@@ -1120,60 +1171,105 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
       }
   };
   if constexpr (GROUPS) {
-    if (!L.resume) add_group_forces(load_agent_consts(late_args(), F32));  // a class record's force already has them
+    if (!L.resume) add_group_forces(k0, load_agent_consts(late_args(), F32));  // a class record's force already has them
   }
 
   const int rows = A / 2;            // half ring; for even A the last row is half length
   const bool even = (A & 1) == 0;
-  // byte offset (within a plane) of the partner each slot meets next, and its wrap bound:
-  // the partner walks i+1, i+2, ... inside the slot's own sample
-  int jo_[NS], hi_[NS];
+  // byte offset (within a plane) of the partner each slot meets next: the partner walks i+1, i+2, ... inside the slot's own
+  // sample, i.e. from the word behind the sample's last agent (hi_) back to its first (lo_)
+  uint32_t jo_[NS], hi_[NS], lo_[NS];
 #pragma unroll
-  for (int r = 0; r < NS; ++r) hi_[r] = 8 * (sl_[r] - i_[r] + A);
-  const int wrap = 8 * A;
+  for (int r = 0; r < NS; ++r) {
+    lo_[r] = 8u * static_cast<uint32_t>(sl_[r] - i_[r]);
+    hi_[r] = lo_[r] + 8u * static_cast<uint32_t>(A);
+  }
   // byte offset of this lane's half record inside a row of the robot-step table (a chunk's row is < 4 GB: one VGPR)
   uint32_t rs_off = 0;
   if (lane < 2 * Gn)
     rs_off = static_cast<uint32_t>(robot_sample_of_item(L, first_local + (lane >> 1)) * static_cast<int64_t>(sizeof(sfw_robot_step))) +
              16u * (lane & 1);
 
+  // Every load of the prologue has landed before the first step, and every scratch reload of a step before the next (the
+  // builtin, unlike an asm string, is seen by the compiler's wait-count pass): otherwise the pass, merging the loop's entry
+  // and back edges, puts an s_waitcnt vmcnt(0) in front of the first use of such a register inside the row loop, where it
+  // also waits for the LDS-direct load of the robot records that is meant to stay in flight during the pair pass.
+  constexpr int WAIT_VMCNT0 = 0x0F70;  // gfx9 s_waitcnt encoding: vmcnt(0), expcnt and lgkmcnt left alone
+  __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
   for (int step = step_begin; step < step_end; ++step) {
+    // The pair term's constants are (re)built per step: the ones pinned to VGPRs are opaque to the compiler, which can only
+    // spill what it cannot rematerialise — held across the rollout, the asin polynomial's leading coefficient went to scratch
+    // around the laser-point loop and came back with a wait inside the row loop.
+    const sfm_consts<R> k = make_consts<R, false>(late_args());
     // This step's robot records (32 B per sample, contiguous) go from the K1 table straight to
     // LDS (global_load_lds_dwordx4: no VGPRs), in flight during the pair pass.  The waves of a
     // launch start together and run the same instruction stream, so a load issued where it is
     // consumed stalls every resident wave of the SIMD at once (14 % of wave time in s_waitcnt
     // at cfg2 before this, profiles/r01e).  Lane l < 2 Gn brings half (l & 1) of sample (l >> 1)'s record from
     // the step's table row (a scalar base) plus its own byte offset, fixed for the rollout (G <= 32, plan_for; forming the address from the item
-    // tables every step cost ~90 and, at 80 VGPRs, the scratch spills around it).
+    // tables every step cost ~90 and, at 80 VGPRs, the scratch spills around it).  The pair pass below holds no
+    // compiler-visible DS or VMEM instruction (lds_pair_state, lds_add_pair), so nothing in it waits for this load.
+#if defined(SFW_ABL_NOROBOT)
+    if (step == step_begin)
+#endif
     if (lane < 2 * Gn)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(L.rstep + static_cast<int64_t>(step) * L.rstep_stride) + rs_off),
           (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(s.rsb)), 16, 0, 0);
     // ---- pair pass: social forces at the pre-step state -------------------
+    // one pair of slot r with the partner at plane offset jo
+    auto pair_with = [&](int r, uint32_t jo) {
+      R qx, qy;
+      double pix, piy, vix, viy, pjx, pjy, vjx, vjy;
+#if defined(SFW_ABL_NOREAD)
+      pix = fx[r]; piy = fy[r]; vix = sw[r] + 1.0; viy = 0.5; pjx = fx[r] + static_cast<double>(jo); pjy = fy[r] - 3.0; vjx = 0.25; vjy = static_cast<double>(jo) * 0.001;
+#else
+      lds_pair_state<PY, VX, VY>(io_[r], jo, pix, piy, vix, viy, pjx, pjy, vjx, vjy);
+#endif
+#if defined(SFW_ABL_NOMATH)
+      qx = R(pix + pjy - vjx); qy = R(piy - pjx + vix * viy + vjy);
+#else
+      pair_force_state<R>(k, pix, piy, vix, viy, pjx, pjy, vjx, vjy, qx, qy);
+#endif
+      fx[r] += static_cast<double>(qx);
+      fy[r] += static_cast<double>(qy);
+      // the partner receives -q: accumulated with the opposite sign, subtracted in the agent pass
+#if !defined(SFW_ABL_NOATOM)
+      lds_add_pair<FJX, FJY>(jo, static_cast<double>(qx), static_cast<double>(qy));
+#endif
+    };
+    // the partner offset advances by one word per row, so it can only MEET the bound
+    auto next_partner = [&](int r) {
+      uint32_t jo = jo_[r] + 8u;
+      jo = (jo == hi_[r]) ? lo_[r] : jo;
+      jo_[r] = jo;
+      return jo;
+    };
 #pragma unroll
-    for (int r = 0; r < NS; ++r) jo_[r] = 8 * sl_[r];
-    for (int row = 0; row < rows; ++row) {
-      const bool half = even && (row == rows - 1);
+    for (int r = 0; r < NS; ++r) jo_[r] = io_[r];
+    if constexpr (NS == 1) {
+      // One slot per lane: the lane mask of the full rows is the same for every row (the lanes that own a slot), so it is
+      // set ONCE around the loop; the half row of an even agent count is peeled off with its own mask.  Written with the
+      // mask inside the loop, every row paid 14 scalar instructions of mask arithmetic and a branch.
+      if (ok_[0]) {
+        const int full_rows = even ? rows - 1 : rows;
+        for (int row = 0; row < full_rows; ++row) pair_with(0, next_partner(0));
+        if (even && rows > 0) {
+          const uint32_t jo = next_partner(0);
+          if (i_[0] < rows) pair_with(0, jo);
+        }
+      }
+    } else {
+      for (int row = 0; row < rows; ++row) {
+        const bool half = even && (row == rows - 1);
 #pragma unroll
-      for (int r = 0; r < NS; ++r) {
-        int jo = jo_[r] + 8;
-        jo = (jo >= hi_[r]) ? jo - wrap : jo;
-        jo_[r] = jo;
-        if (ok_[r] && !(half && i_[r] >= rows)) {
-          const int io = 8 * sl_[r];
-          R qx, qy;
-          double pix, piy, vix, viy, pjx, pjy, vjx, vjy;
-          lds_pair_state<PY, VX, VY>(static_cast<uint32_t>(io), static_cast<uint32_t>(jo), pix, piy, vix, viy, pjx, pjy, vjx, vjy);
-          pair_force_state<R>(k, pix, piy, vix, viy, pjx, pjy, vjx, vjy, qx, qy);
-          fx[r] += static_cast<double>(qx);
-          fy[r] += static_cast<double>(qy);
-          // the partner receives -q: accumulated with the opposite sign, subtracted in the agent pass
-          atomicAdd(&lds_at<double>(smem, jo + FJX), static_cast<double>(qx));
-          atomicAdd(&lds_at<double>(smem, jo + FJY), static_cast<double>(qy));
+        for (int r = 0; r < NS; ++r) {
+          const uint32_t jo = next_partner(r);
+          if (ok_[r] && !(half && i_[r] >= rows)) pair_with(r, jo);
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct load above has landed
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the LDS-direct load above has landed, the row loop's atomics are done
     __syncthreads();
 
     // ---- per-agent pass ---------------------------------------------------
@@ -1183,34 +1279,49 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     const bool with_obs = c.O > 0;
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
-      if (ok_[r] && s.dead[g_[r]] == 0) {
-        const int sl = sl_[r];
-        const sfw_robot_step rs = s.rsb[g_[r]];
-        double px = s.px[sl], py = s.py[sl], vx = s.vx[sl], vy = s.vy[sl];
+#if defined(SFW_ABL_NOAGENT)
+      if (false) {
+#else
+      if (ok_[r] && lds_at<int>(smem, off::DEAD + g4_[r]) == 0) {
+#endif
+        const uint32_t io = io_[r], ci = ci_[r];
+        const bool robot = i_[r] == 0;
+        const sfw_robot_step rs = lds_at<sfw_robot_step>(smem, off::RSB + 8u * g4_[r]);
+        double px = lds_at<double>(smem, io), py = lds_at<double>(smem, io + PY), vx = lds_at<double>(smem, io + VX),
+               vy = lds_at<double>(smem, io + VY);
+        const double2 goal = lds_at<double2>(smem, ci), grdv = lds_at<double2>(smem, ci + 16u);
+        const agent_k ak{goal.x, goal.y, grdv.x, grdv.y, 0.0, 0};
+        const int2 cell = lds_at<int2>(smem, io + off::HG);
+        int hg = cell.x;
+        bool contact;
         double nfx, nfy;
-        const double w = agent_step<R>(k, c, s, rs, agent_k_lds(s, i_[r]), step, i_[r], g_[r], sl, px, py, vx, vy,
-                                       fx[r] - s.fjx[sl], fy[r] - s.fjy[sl], nfx, nfy);
+        const double w = agent_step<R>(k, c, rs, ak, robot, cell.y != 0, hg, contact, px, py, vx, vy,
+                                       fx[r] - lds_at<double>(smem, io + FJX), fy[r] - lds_at<double>(smem, io + FJY), nfx, nfy);
+        if (hg != cell.x) lds_at<int>(smem, io + off::HG) = hg;  // goal reached: popped
+#if !defined(SFW_ABL_NOATOM) && !defined(SFW_ABL_NOREAD) && !defined(SFW_ABL_NOMATH) && !defined(SFW_ABL_KEEPALIVE)
+        if (contact) lds_at<int>(smem, off::DEAD + g4_[r]) = 2 + step;  // >= 2: rejected by contact at `step`
+#endif
         fx[r] = nfx;
         fy[r] = nfy;
-        if (i_[r] == 0 && with_obs) {
-          s.swp[sl] = w;  // Wr = social part + obstacle part, summed in (2) before it joins the social work
+        if (robot && with_obs) {
+          lds_at<double>(smem, io + off::SW) = w;  // Wr = social part + obstacle part, summed in (2) before it joins the social work
         } else {
           sw[r] += w;
         }
-        if (i_[r] == 0) {  // the robot does not move by SFM: post-step record (ref :600, :604 robot-local twist)
+        if (robot) {  // the robot does not move by SFM: post-step record (ref :600, :604 robot-local twist)
           px = rs.x;
           py = rs.y;
           vx = rs.vx;
           vy = rs.vy;
         }
-        if (!(i_[r] == 0 && with_obs)) {
-          s.px[sl] = px;
-          s.py[sl] = py;
-          s.vx[sl] = vx;
-          s.vy[sl] = vy;
+        if (!(robot && with_obs)) {
+          lds_at<double>(smem, io) = px;
+          lds_at<double>(smem, io + PY) = py;
+          lds_at<double>(smem, io + VX) = vx;
+          lds_at<double>(smem, io + VY) = vy;
         }
-        s.fjx[sl] = 0.0;
-        s.fjy[sl] = 0.0;
+        lds_at<double>(smem, io + FJX) = 0.0;
+        lds_at<double>(smem, io + FJY) = 0.0;
       }
     }
     // (2) obstacle term, ONE loop over the laser points for every lane of the wave: the robot needs it at its
@@ -1218,17 +1329,18 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     if (with_obs) {
 #pragma unroll
       for (int r = 0; r < NS; ++r)
-        if (ok_[r] && s.dead[g_[r]] == 0) {
-          const int sl = sl_[r];
+        if (ok_[r] && lds_at<int>(smem, off::DEAD + g4_[r]) == 0) {
+          const uint32_t io = io_[r];
           double ox, oy;
-          obstacle_force<R>(k, c, s.obs, s.px[sl], s.py[sl], s.rad[i_[r]], ox, oy);
+          obstacle_force<R>(k, c, s.obs, lds_at<double>(smem, io), lds_at<double>(smem, io + PY),
+                            lds_at<double>(smem, ci_[r] + 32u), ox, oy);
           if (i_[r] == 0) {
-            sw[r] += s.swp[sl] + fast_norm(ox, oy);
-            const sfw_robot_step r2 = s.rsb[g_[r]];
-            s.px[sl] = r2.x;
-            s.py[sl] = r2.y;
-            s.vx[sl] = r2.vx;
-            s.vy[sl] = r2.vy;
+            sw[r] += lds_at<double>(smem, io + off::SW) + fast_norm(ox, oy);
+            const sfw_robot_step r2 = lds_at<sfw_robot_step>(smem, off::RSB + 8u * g4_[r]);
+            lds_at<double>(smem, io) = r2.x;
+            lds_at<double>(smem, io + PY) = r2.y;
+            lds_at<double>(smem, io + VX) = r2.vx;
+            lds_at<double>(smem, io + VY) = r2.vy;
           } else {
             fx[r] += ox;
             fy[r] += oy;
@@ -1239,8 +1351,8 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     bool any_live = false;
     for (int g = 0; g < G; ++g) any_live |= (s.dead[g] == 0);
     if (!any_live) break;
-    if constexpr (GROUPS) add_group_forces(c);
-  }
+    if constexpr (GROUPS) add_group_forces(k, c);
+      }
 
   const late_launch Le = late_args();
   if (Le->phase == SFW_PHASE_PREFIX) {  // leave the class records
@@ -1251,7 +1363,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         sfw_cls_agent c;
         c.px = s.px[sl_[r]]; c.py = s.py[sl_[r]]; c.vx = s.vx[sl_[r]]; c.vy = s.vy[sl_[r]];
         c.fx = fx[r]; c.fy = fy[r]; c.sw = sw[r];
-        c.hasgoal = s.hasgoal[sl_[r]];
+        c.hasgoal = s.hg(sl_[r]);
         c.pad = 0;
         out_state[(first_local + g_[r]) * A + i_[r]] = c;
       }
@@ -1489,8 +1601,13 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       const agent_k ak = GROUPS ? agent_k_lds(s, sl) : agent_k_global(agent_c, sl);
       double px = s.px[sl], py = s.py[sl], vx = s.vx[sl], vy = s.vy[sl];
       double nfx, nfy;
-      const double w = agent_step<R>(k, c, s, rs, ak, step, sl, 0, sl, px, py, vx, vy, s.fcx[sl] - s.fjx[sl],
-                                            s.fcy[sl] - s.fjy[sl], nfx, nfy);
+      int hg = s.hasgoal[sl];
+      const int hg0 = hg;
+      bool contact;
+      const double w = agent_step<R>(k, c, rs, ak, sl == 0, ak.id != c.robot_id, hg, contact, px, py, vx, vy,
+                                     s.fcx[sl] - s.fjx[sl], s.fcy[sl] - s.fjy[sl], nfx, nfy);
+      if (sl != 0 && hg0) s.hasgoal[sl] = hg;
+      if (contact) s.dead[0] = 2 + step;  // >= 2: rejected by contact at `step`
       if (sl == 0 && with_obs) {
         *s.wr = w;  // Wr = social part + obstacle part: summed below, then added to the robot's social work
       } else {
@@ -1534,7 +1651,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
           const int a = a0 + (lane >> 3);
           R ax = R(0), ay = R(0);
           if (a < A) {
-            const double rad = GROUPS ? s.rad[a] : agent_c[a].radius;
+            const double rad = GROUPS ? s.ac[a].radius : agent_c[a].radius;
             obstacle_segment<R>(k, s.obs, ob, oe, s.px[a], s.py[a], obstacle_c0<R>(c, rad), nis, ax, ay);
           }
           s.opart[lane] = double2{static_cast<double>(ax), static_cast<double>(ay)};
@@ -1552,7 +1669,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
         }
       } else {
         for (int a = lane; a < A; a += WAVE) {
-          const double rad = GROUPS ? s.rad[a] : agent_c[a].radius;
+          const double rad = GROUPS ? s.ac[a].radius : agent_c[a].radius;
           double ox, oy;
           obstacle_force<R>(k, c, s.obs, s.px[a], s.py[a], rad, ox, oy);
           apply(a, ox, oy);
