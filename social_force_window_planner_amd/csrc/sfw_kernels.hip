@@ -1076,7 +1076,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   clock_probe(0);
 
   // ---- this lane's slots --------------------------------------------------
-  // A slot is addressed through three registers for the whole rollout: io = 8 * slot (the planes, its {hasgoal, Wp}
+  // A slot is addressed through three registers for the whole rollout: io = 8 * slot (the planes, its {hasgoal, 2 i + Wp}
   // cell and its social-work word at the fixed distances of reg_off), ci = the LDS address of its agent's constants,
   // g4 = 4 * sample (contact flag at off::DEAD, robot record at off::RSB + 8 * g4).
   int sl_[NS], g_[NS], i_[NS];
@@ -1103,7 +1103,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
       const int i = i_[r];
       fx[r] = fy[r] = sw[r] = 0.0;
       // the slot's Wp switch: a person whose id is not the robot's receives the robot-on-person term (ref :692)
-      const int wp_on = (i != 0 && s.ac[i].id != c0.robot_id) ? 1 : 0;
+      const int wp_on = (i << 1) | ((i != 0 && s.ac[i].id != c0.robot_id) ? 1 : 0);  // + the agent index (epilogue)
       if (L.resume) {  // resume from the record of the item's (parent) class
         if (ok_[r] && g_[r] < Gn) {
           const sfw_cls_agent c = L.in_state[source_class_of_item(L, first_local + g_[r]) * A + i];
@@ -1295,7 +1295,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         int hg = cell.x;
         bool contact;
         double nfx, nfy;
-        const double w = agent_step<R>(k, c, rs, ak, robot, cell.y != 0, hg, contact, px, py, vx, vy,
+        const double w = agent_step<R>(k, c, rs, ak, robot, (cell.y & 1) != 0, hg, contact, px, py, vx, vy,
                                        fx[r] - lds_at<double>(smem, io + FJX), fy[r] - lds_at<double>(smem, io + FJY), nfx, nfy);
         if (hg != cell.x) lds_at<int>(smem, io + off::HG) = hg;  // goal reached: popped
 #if !defined(SFW_ABL_NOATOM) && !defined(SFW_ABL_NOREAD) && !defined(SFW_ABL_NOMATH) && !defined(SFW_ABL_KEEPALIVE)
@@ -1357,15 +1357,22 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   const late_launch Le = late_args();
   if (Le->phase == SFW_PHASE_PREFIX) {  // leave the class records
     sfw_cls_agent *const out_state = Le->out_state;
+    // The record index is formed HERE from values the rollout keeps anyway (4 * sample, the late-read A, the agent index
+    // parked in the slot's cell): computed from L.A and i_ it is the same expression as the prologue's resume index, and
+    // the compiler kept that 64-bit value in scratch across the whole rollout.
+    const int64_t A_late = Le->A;
 #pragma unroll
     for (int r = 0; r < NS; ++r)
-      if (ok_[r] && g_[r] < Gn) {
+      if (ok_[r] && static_cast<int>(g4_[r] >> 2) < Gn) {
+        const uint32_t io = io_[r];
         sfw_cls_agent c;
-        c.px = s.px[sl_[r]]; c.py = s.py[sl_[r]]; c.vx = s.vx[sl_[r]]; c.vy = s.vy[sl_[r]];
+        c.px = lds_at<double>(smem, io); c.py = lds_at<double>(smem, io + PY);
+        c.vx = lds_at<double>(smem, io + VX); c.vy = lds_at<double>(smem, io + VY);
         c.fx = fx[r]; c.fy = fy[r]; c.sw = sw[r];
-        c.hasgoal = s.hg(sl_[r]);
+        const int2 cell = lds_at<int2>(smem, io + off::HG);
+        c.hasgoal = cell.x;
         c.pad = 0;
-        out_state[(first_local + g_[r]) * A + i_[r]] = c;
+        out_state[(first_local + static_cast<int64_t>(g4_[r] >> 2)) * A_late + (cell.y >> 1)] = c;
       }
     if (lane < Gn) Le->out_dead[first_local + lane] = s.dead[lane];
     clock_probe(1);
@@ -1375,7 +1382,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
 #pragma unroll
   for (int r = 0; r < NS; ++r) {
     if (G == 1) sw_acc += ok_[r] ? sw[r] : 0.0;
-    else if (ok_[r]) s.swp[sl_[r]] = sw[r];
+    else if (ok_[r]) lds_at<double>(smem, io_[r] + off::SW) = sw[r];
   }
   finish_wave(s, lane, G, Gn, first_local, sw_acc);
   clock_probe(1);
@@ -1964,6 +1971,15 @@ template <typename K> static hipError_t launch_social_as(K kernel, const sfw_lau
   return hipGetLastError();
 }
 
+// reg_off<CAP> restates where lds_layout puts the register form's fixed part: checked once per process.
+template <int CAP> static bool reg_layout_matches() {
+  const lds_layout s(nullptr, 5, CAP, 10, 2, 3, 0, 0, true, false);
+  auto at = [&](const void *p) { return static_cast<int>(reinterpret_cast<const char *>(p) - reinterpret_cast<const char *>(s.px)); };
+  using off = reg_off<CAP>;
+  return at(s.py) == off::PY && at(s.vx) == off::VX && at(s.vy) == off::VY && at(s.fjx) == off::FJX && at(s.fjy) == off::FJY &&
+         at(s.hasgoal) == off::HG && at(s.swp) == off::SW && at(s.dead) == off::DEAD && at(s.rsb) == off::RSB && s.hg_stride == 2;
+}
+
 template <typename R> static hipError_t launch_social_typed(const sfw_launch &L, hipStream_t stream) {
   // The organisations are bit-identical and the class records of the shared-prefix rollout are
   // organisation-neutral, so every launch picks its own by its item count (measured: forcing the
@@ -1973,6 +1989,8 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L,
   const unsigned grid = static_cast<unsigned>((items + pl.G - 1) / pl.G);
   const size_t lds = lds_bytes_for(pl, L.A, L.O, L.NG, L.n_grp_mem);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static const bool layout_ok = reg_layout_matches<WAVE>() && reg_layout_matches<2 * WAVE>();
+  if (!layout_ok) return hipErrorInvalidValue;
   const bool groups = L.NG > 0;  // at least one agent carries a group id: kernels with the group pass
   if (pl.flat) {
     if (8 * (static_cast<int64_t>(L.A) + 1) > 65535 || !L.pair_tab) return hipErrorInvalidValue;  // 16-bit plane offsets
