@@ -1561,18 +1561,30 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     R qx, qy;
     if constexpr (CAP > 0) {
       double pix, piy, vix, viy, pjx, pjy, vjx, vjy;
+#if defined(SFW_ABL_NOREAD)
+      pix = static_cast<double>(io); piy = 1.0; vix = 0.3; viy = 0.5; pjx = static_cast<double>(jo) * 0.37; pjy = -3.0; vjx = 0.25; vjy = static_cast<double>(jo) * 0.001;
+#else
       lds_pair_state<8 * CAP, 16 * CAP, 24 * CAP>(io, jo, pix, piy, vix, viy, pjx, pjy, vjx, vjy);
+#endif
+#if defined(SFW_ABL_NOMATH)
+      qx = R(pix + pjy - vjx); qy = R(piy - pjx + vix * viy + vjy);
+#else
       pair_force_state<R>(k, pix, piy, vix, viy, pjx, pjy, vjx, vjy, qx, qy);
+#endif
     } else {
       pair_force_state<R>(k, lds_at<double>(smem, io), lds_at<double>(smem, io + PY), lds_at<double>(smem, io + VX),
                           lds_at<double>(smem, io + VY), lds_at<double>(smem, jo), lds_at<double>(smem, jo + PY),
                           lds_at<double>(smem, jo + VX), lds_at<double>(smem, jo + VY), qx, qy);
     }
+#if defined(SFW_ABL_NOATOM)
+    asm volatile("" :: "v"(qx), "v"(qy));
+#else
     atomicAdd(&lds_at<double>(smem, io + FCX), static_cast<double>(qx));
     atomicAdd(&lds_at<double>(smem, io + FCY), static_cast<double>(qy));
     // j receives -q: accumulated with the opposite sign, subtracted in the agent pass
     atomicAdd(&lds_at<double>(smem, jo + FJX), static_cast<double>(qx));
     atomicAdd(&lds_at<double>(smem, jo + FJY), static_cast<double>(qy));
+#endif
   };
 
   for (int step = step_begin; step < step_end; ++step) {
@@ -1604,7 +1616,11 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     const sfw_robot_step rs = s.rsb[step & 1];
     if (step + 1 < step_end) fetch_robot(La->rstep, La->rstep_stride, step + 1, (step + 1) & 1);
     const bool with_obs = c.O > 0;
+#if defined(SFW_ABL_NOAGENT)
+    for (int sl = lane; sl < 0; sl += WAVE) {
+#else
     for (int sl = lane; sl < A; sl += WAVE) {
+#endif
       const agent_k ak = GROUPS ? agent_k_lds(s, sl) : agent_k_global(agent_c, sl);
       double px = s.px[sl], py = s.py[sl], vx = s.vx[sl], vy = s.vy[sl];
       double nfx, nfy;
@@ -1614,7 +1630,9 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       const double w = agent_step<R>(k, c, rs, ak, sl == 0, ak.id != c.robot_id, hg, contact, px, py, vx, vy,
                                      s.fcx[sl] - s.fjx[sl], s.fcy[sl] - s.fjy[sl], nfx, nfy);
       if (sl != 0 && hg0) s.hasgoal[sl] = hg;
+#if !defined(SFW_ABL_NOATOM) && !defined(SFW_ABL_NOREAD) && !defined(SFW_ABL_NOMATH) && !defined(SFW_ABL_KEEPALIVE)
       if (contact) s.dead[0] = 2 + step;  // >= 2: rejected by contact at `step`
+#endif
       if (sl == 0 && with_obs) {
         *s.wr = w;  // Wr = social part + obstacle part: summed below, then added to the robot's social work
       } else {
