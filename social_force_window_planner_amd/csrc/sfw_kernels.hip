@@ -680,7 +680,8 @@ struct lds_layout {
   double *swp;
   double2 *opart;       // flat form with laser points: the 64 lanes' partial obstacle sums of one pass
   double *wr;           // flat form with laser points: the robot's social-work term waiting for its obstacle part
-  int *hasgoal, *dead, *grp, *goff, *gmem;
+  int *hasgoal, *dead, *grp, *goff, *gmem;  // hasgoal: register form (one int per 8-byte cell)
+  unsigned char *hasgoal8;  // flat form: one byte per agent (crowds of 129..255 agents are LDS-bound in occupancy)
   int hg_stride;        // ints between two slots' hasgoal words (see hg())
   size_t bytes;
   // Register form (with_frc = false): everything a slot reads and writes every step sits at a COMPILE-TIME distance from
@@ -713,7 +714,8 @@ struct lds_layout {
       swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
       opart = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? 64 : 0)));
       wr = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? 2 : 0)));
-      hasgoal = reinterpret_cast<int *>(take(sizeof(int) * GA));
+      hasgoal8 = reinterpret_cast<unsigned char *>(take(static_cast<size_t>(GA)));
+      hasgoal = nullptr;
       hg_stride = 1;
       dead = reinterpret_cast<int *>(take(sizeof(int) * G));
     } else {         // register form: fixed distances first (reg_off below restates them)
@@ -721,6 +723,7 @@ struct lds_layout {
       opart = nullptr;
       wr = nullptr;
       hasgoal = reinterpret_cast<int *>(take(plane));
+      hasgoal8 = nullptr;
       hg_stride = 2;
       swp = reinterpret_cast<double *>(take(plane));
       dead = reinterpret_cast<int *>(take(sizeof(int) * REG_DEAD_CAP));
@@ -735,7 +738,7 @@ struct lds_layout {
     gmem = reinterpret_cast<int *>(take(sizeof(int) * (NG > 0 && NM > 0 ? NM : 0)));
     bytes = static_cast<size_t>(base - base0);
   }
-  __device__ __forceinline__ int &hg(int sl) const { return hasgoal[sl * hg_stride]; }
+  __device__ __forceinline__ int hg(int sl) const { return hg_stride == 1 ? static_cast<int>(hasgoal8[sl]) : hasgoal[sl * hg_stride]; }
 };
 // Byte offsets of the register form's fixed part from a slot's px word (CAP = 64 * NS doubles per plane).
 template <int CAP> struct reg_off {
@@ -1473,7 +1476,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       s.py[sl] = c.py;
       s.vx[sl] = c.vx;
       s.vy[sl] = c.vy;
-      s.hasgoal[sl] = c.hasgoal;
+      s.hasgoal8[sl] = static_cast<unsigned char>(c.hasgoal != 0);
       s.swp[sl] = c.sw;
       s.fcx[sl] = c.fx;
       s.fcy[sl] = c.fy;
@@ -1489,7 +1492,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       s.py[sl] = py;
       s.vx[sl] = vx;
       s.vy[sl] = vy;
-      s.hasgoal[sl] = c.has_goal;
+      s.hasgoal8[sl] = static_cast<unsigned char>(c.has_goal != 0);
       s.swp[sl] = 0.0;
       double fx = 0.0, fy = 0.0;
       if (sl != 0) {
@@ -1624,12 +1627,12 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       const agent_k ak = GROUPS ? agent_k_lds(s, sl) : agent_k_global(agent_c, sl);
       double px = s.px[sl], py = s.py[sl], vx = s.vx[sl], vy = s.vy[sl];
       double nfx, nfy;
-      int hg = s.hasgoal[sl];
+      int hg = s.hasgoal8[sl];
       const int hg0 = hg;
       bool contact;
       const double w = agent_step<R>(k, c, rs, ak, sl == 0, ak.id != c.robot_id, hg, contact, px, py, vx, vy,
                                      s.fcx[sl] - s.fjx[sl], s.fcy[sl] - s.fjy[sl], nfx, nfy);
-      if (sl != 0 && hg0) s.hasgoal[sl] = hg;
+      if (sl != 0 && hg0) s.hasgoal8[sl] = static_cast<unsigned char>(hg);
 #if !defined(SFW_ABL_NOATOM) && !defined(SFW_ABL_NOREAD) && !defined(SFW_ABL_NOMATH) && !defined(SFW_ABL_KEEPALIVE)
       if (contact) s.dead[0] = 2 + step;  // >= 2: rejected by contact at `step`
 #endif
@@ -1720,7 +1723,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       sfw_cls_agent c;
       c.px = s.px[sl]; c.py = s.py[sl]; c.vx = s.vx[sl]; c.vy = s.vy[sl];
       c.fx = s.fcx[sl]; c.fy = s.fcy[sl]; c.sw = s.swp[sl];
-      c.hasgoal = s.hasgoal[sl];
+      c.hasgoal = s.hasgoal8[sl];
       c.pad = 0;
       rec[sl] = c;
     }
@@ -1909,7 +1912,9 @@ void sfw_derive(sfw_launch &L) {
 
 // Capacity (doubles per LDS plane) of the flat kernel for A agents: compile-time 64 / 128 / 256 when A fits with
 // one record to spare (the dummy slot of the padded pair table), otherwise 0 = run-time (A + 1 rounded up to even).
-static int flat_cap(int A) { return A < 64 ? 64 : A < 128 ? 128 : A < 256 ? 256 : 0; }
+// 208: crowds of 128..207 agents (BASELINE cfg4: 201) keep their plane distances as immediates AND fit ten waves per CU
+// (8 planes x 208 x 8 B + 2.4 KB < 15 KB; with 256-double planes 19 KB: eight)
+static int flat_cap(int A) { return A < 64 ? 64 : A < 104 ? 104 : A < 128 ? 128 : A < 208 ? 208 : A < 256 ? 256 : 0; }
 static int flat_cap_runtime(int A) { return (A + 2) & ~1; }
 
 static size_t lds_bytes_for(const wave_plan &pl, int A, int O, int NG, int n_grp_mem) {
@@ -2016,9 +2021,15 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L,
       case 64:
         return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 64>, L, 1, grid, lds, stream)
                       : launch_social_as(sfw_social_kernel_flat<R, false, 64>, L, 1, grid, lds, stream);
+      case 104:
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 104>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 104>, L, 1, grid, lds, stream);
       case 128:
         return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 128>, L, 1, grid, lds, stream)
                       : launch_social_as(sfw_social_kernel_flat<R, false, 128>, L, 1, grid, lds, stream);
+      case 208:
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 208>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 208>, L, 1, grid, lds, stream);
       case 256:
         return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 256>, L, 1, grid, lds, stream)
                       : launch_social_as(sfw_social_kernel_flat<R, false, 256>, L, 1, grid, lds, stream);
