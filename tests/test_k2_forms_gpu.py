@@ -84,6 +84,26 @@ def test_agent_counts(oracle_mod, hip_mod, n_people, form, prec, rtol):
     _check(oracle_mod, hip_mod, syn.make_scene(w), form, prec, rtol)
 
 
+# (b') crowds beyond the register form (A > 128): every plane capacity of the flat kernel — 208 doubles (A = 151, and 208 = its
+#      last agent count + the dummy slot ... A = 207), 256 (A = 208, 231), run-time (A = 301)
+@pytest.mark.parametrize("n_people", [150, 206, 207, 230, 300])
+def test_large_crowd_plane_capacities(oracle_mod, hip_mod, n_people):
+    w = dataclasses.replace(syn.WORKLOADS["cfg4"], nv=4, nw=5, n_people=n_people, seed=900 + n_people, sim_time=0.5)
+    scene = syn.make_scene(w)
+    kw = dict(sim_time=w.sim_time, sim_granularity=w.sim_granularity)
+    o = oracle_mod.OracleScorer(default_params(**kw))
+    o.load_scene(scene)
+    g = hip_mod.HipScorer(default_params(**kw))
+    g.load_scene(scene)
+    g.stage(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    assert g.plan_info()["organisation"] == SFW_ORG_FLAT
+    g.launch()
+    gc, gb, _ = g.fetch()
+    oc, ob = o.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args, n_threads=32)
+    assert (oc >= 0).sum() >= 4, "scene has too few valid samples to say anything"
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
 # (c) pairs at exact relative rest (the host-evaluated angular terms, L.agent_rest, are added in both organisations)
 @pytest.mark.parametrize("prec,rtol", PRECISIONS)
 @pytest.mark.parametrize("form", FORMS)

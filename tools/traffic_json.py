@@ -2,7 +2,8 @@
 usage: traffic_json.py <workload>=<traffic.txt> ... > profiles/r02_traffic.json
 The summaries hold means per dispatch; a bench step dispatches K2 several times (shared-prefix levels +
 suffix, possibly in both kernel organisations), so bytes are converted to per-step sums using the
-dispatch counts (one sfw_rollout_kernel dispatch per step)."""
+dispatch counts (one sfw_costmap_scan_kernel dispatch per step; sfw_rollout_kernel also runs in stage-only calls, e.g.
+bench.py's plan query, since the stage enqueues it)."""
 import json
 import re
 import sys
@@ -20,10 +21,13 @@ for arg in sys.argv[1:]:
         if m and cur is not None:
             cur["fetch_bytes" if m.group(1) == "FETCH_SIZE" else "write_bytes"] = float(m.group(2)) * 1024.0
     kernels = {k: v for k, v in kernels.items() if "pair_table" not in k}
-    steps = next(v["dispatches"] for k, v in kernels.items() if k.startswith("sfw_rollout_kernel"))
+    per_step_kernel = "sfw_costmap_scan_kernel" if any(k.startswith("sfw_costmap_scan_kernel") for k in kernels) else "sfw_rollout_kernel"
+    steps = next(v["dispatches"] for k, v in kernels.items() if k.startswith(per_step_kernel))
     per_step = {}
     for k, v in kernels.items():
         n = v["dispatches"] / steps
+        if k.startswith("sfw_rollout_kernel"):
+            n = 1.0  # once per step; the surplus dispatches are stage-only calls outside any step
         per_step[k] = {"dispatches_per_step": n, "fetch_bytes": v.get("fetch_bytes", 0.0) * n,
                        "write_bytes": v.get("write_bytes", 0.0) * n}
     k2 = [k for k in per_step if "social" in k]
