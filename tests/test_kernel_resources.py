@@ -1,0 +1,57 @@
+"""Register / scratch budget of the K2 kernels, read from the compiler's own resource remarks (no GPU needed: hipcc
+cross-compiles gfx950).  The occupancy the launch plan counts on is a property of the build, so it is pinned here:
+
+* the register-resident form (f64, one slot per lane, no groups) fits six waves per SIMD — at most 80 VGPRs — WITHOUT
+  scratch (VERDICT r2 "next round" 3; the round-2 build kept 80 bytes per lane there, reloaded one after the other in every
+  per-agent pass);
+* the flat form of the north-star crowd (f64, 64-double planes) fits five waves per SIMD (at most 96 VGPRs) without scratch.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "social_force_window_planner_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def resources():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only",
+                        "-Rpass-analysis=kernel-resource-usage", "-c", "sfw_kernels.hip", "-o", os.devnull],
+                       cwd=CSRC, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        for key, pat in (("vgpr", r"remark:\s+VGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    return out
+
+
+def _kernel(resources, fragment):
+    names = [n for n in resources if fragment in n]
+    assert len(names) == 1, (fragment, names)
+    return resources[names[0]]
+
+
+def test_register_form_six_waves_without_scratch(resources):
+    k = _kernel(resources, "sfw_social_kernelIdLi1ELb0E")
+    assert k["vgpr"] <= 80 and k["scratch"] == 0 and k["occupancy"] >= 6, k
+
+
+def test_flat_form_five_waves_without_scratch(resources):
+    for cap in (64, 104, 128, 208, 256):
+        k = _kernel(resources, f"sfw_social_kernel_flatIdLb0ELi{cap}E")
+        assert k["vgpr"] <= 96 and k["scratch"] == 0 and k["occupancy"] >= 5, (cap, k)
