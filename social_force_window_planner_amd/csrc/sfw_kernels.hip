@@ -1455,6 +1455,8 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
   const int cap = CAP > 0 ? CAP : ((A + 2) & ~1);  // > A: the dummy slot of the padded pair table
   const int PY = 8 * cap, VX = 16 * cap, VY = 24 * cap, FJX = 32 * cap, FJY = 40 * cap, FCX = 48 * cap,
             FCY = 56 * cap;  // byte offsets from px[] (immediates when CAP > 0)
+  (void)FCX;
+  (void)FCY;
   const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, GROUPS, true);
   const int64_t first_local = xcd_contiguous(blockIdx.x, gridDim.x);
   const sfm_consts<R> k = make_consts<R, true>(L);
@@ -1559,6 +1561,9 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
   };
   if (step_begin < step_end) fetch_robot(L.rstep, L.rstep_stride, step_begin, step_begin & 1);
 
+#if defined(SFW_ABL_HALF_LDS)
+  double abl_ix = s.px[lane < A ? lane : 0], abl_iy = s.py[lane < A ? lane : 0], abl_fx = 0.0, abl_fy = 0.0;
+#endif
   // one pair per lane: both agents from LDS, the force into both agents' accumulators
   auto pair_at = [&](uint32_t io, uint32_t jo) {
     R qx, qy;
@@ -1566,6 +1571,11 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       double pix, piy, vix, viy, pjx, pjy, vjx, vjy;
 #if defined(SFW_ABL_NOREAD)
       pix = static_cast<double>(io); piy = 1.0; vix = 0.3; viy = 0.5; pjx = static_cast<double>(jo) * 0.37; pjy = -3.0; vjx = 0.25; vjy = static_cast<double>(jo) * 0.001;
+#elif defined(SFW_ABL_HALF_LDS)
+      // upper bound of a lane-stationary organisation: the i side from registers, only the partner's state from LDS
+      pix = abl_ix; piy = abl_iy; vix = 0.3; viy = 0.5;
+      asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:%5\n\tds_read_b64 %2, %4 offset:%6\n\tds_read_b64 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(pjx), "=&v"(pjy), "=&v"(vjx), "=&v"(vjy) : "v"(jo), "n"(8 * CAP), "n"(16 * CAP), "n"(24 * CAP) : "memory");
 #else
       lds_pair_state<8 * CAP, 16 * CAP, 24 * CAP>(io, jo, pix, piy, vix, viy, pjx, pjy, vjx, vjy);
 #endif
@@ -1581,6 +1591,11 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     }
 #if defined(SFW_ABL_NOATOM)
     asm volatile("" :: "v"(qx), "v"(qy));
+#elif defined(SFW_ABL_HALF_LDS)
+    abl_fx += static_cast<double>(qx);
+    abl_fy += static_cast<double>(qy);
+    atomicAdd(&lds_at<double>(smem, jo + FJX), static_cast<double>(qx));
+    atomicAdd(&lds_at<double>(smem, jo + FJY), static_cast<double>(qy));
 #else
     atomicAdd(&lds_at<double>(smem, io + FCX), static_cast<double>(qx));
     atomicAdd(&lds_at<double>(smem, io + FCY), static_cast<double>(qy));
@@ -1612,6 +1627,9 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+#if defined(SFW_ABL_HALF_LDS)
+    if (lane < A) { s.fcx[lane] += abl_fx; s.fcy[lane] += abl_fy; abl_ix = s.px[lane] + 1e-3; abl_iy = s.py[lane]; abl_fx = abl_fy = 0.0; }
+#endif
     // ---- per-agent pass: its parameters are read here, not held across the pair loop -----------
     const late_launch La = late_args();
     const agent_consts c = load_agent_consts(La, F32);
@@ -1633,7 +1651,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       const double w = agent_step<R>(k, c, rs, ak, sl == 0, ak.id != c.robot_id, hg, contact, px, py, vx, vy,
                                      s.fcx[sl] - s.fjx[sl], s.fcy[sl] - s.fjy[sl], nfx, nfy);
       if (sl != 0 && hg0) s.hasgoal8[sl] = static_cast<unsigned char>(hg);
-#if !defined(SFW_ABL_NOATOM) && !defined(SFW_ABL_NOREAD) && !defined(SFW_ABL_NOMATH) && !defined(SFW_ABL_KEEPALIVE)
+#if !defined(SFW_ABL_NOATOM) && !defined(SFW_ABL_NOREAD) && !defined(SFW_ABL_NOMATH) && !defined(SFW_ABL_KEEPALIVE) && !defined(SFW_ABL_HALF_LDS)
       if (contact) s.dead[0] = 2 + step;  // >= 2: rejected by contact at `step`
 #endif
       if (sl == 0 && with_obs) {
