@@ -1409,11 +1409,14 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
 // spends no VALU issue on indices.  The loads are written as asm, one iteration
 // ahead, into two alternating register pairs (loop unrolled by two: no copies).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sfw_pair_table_kernel(uint16_t *tab, int A, int n_entries) {
+// n_dummy: free slots behind the last agent (plane capacity - A >= 1).  The padding lanes of the last iteration are spread
+// over them: with ONE dummy slot all of them added into the same four accumulators — up to 63 same-address ds_add_f64 per
+// instruction, every step (a control cycle with 5 people: 49 of 64 lanes; A = 24 on a full grid: K2 +20 %).
+__global__ void __launch_bounds__(256) sfw_pair_table_kernel(uint16_t *tab, int A, int n_entries, int n_dummy) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_entries) return;
   const int P = A * (A - 1) / 2;
-  int i = A, j = A;  // dummy slot
+  int i = A + (u >= P ? (u - P) % n_dummy : 0), j = i;  // a dummy slot
   if (u < P) {
     const int row = u / A;
     i = u - row * A;
@@ -1515,9 +1518,9 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       s.fjx[sl] = s.fjy[sl] = 0.0;
     }
   }
-  if (lane == 0) {  // the dummy slot: finite state, accumulators nobody reads
-    s.px[A] = s.py[A] = s.vx[A] = s.vy[A] = 0.0;
-    s.fcx[A] = s.fcy[A] = s.fjx[A] = s.fjy[A] = 0.0;
+  for (int sl = A + lane; sl < cap; sl += WAVE) {  // the dummy slots: finite state, accumulators nobody reads
+    s.px[sl] = s.py[sl] = s.vx[sl] = s.vy[sl] = 0.0;
+    s.fcx[sl] = s.fcy[sl] = s.fjx[sl] = s.fjy[sl] = 0.0;
   }
   __syncthreads();
   auto add_group_forces = [&](const agent_consts &c) {
@@ -1860,11 +1863,18 @@ __global__ void __launch_bounds__(64) sfw_key_table_kernel(const sfw_sel *sel, d
 // ===========================================================================
 
 
-// How one wave is organised for A agents (measured on MI355X):
-//   reg  NS=1 : G = floor(64/A) samples per wave, lanes used G*A/64, ~141 VALU/pair
-//   reg  NS=2 : one sample, lanes used A/128 (64 < A <= 128), slightly lower occupancy
-//   flat      : one sample, ~100 % of the lanes but ~20 % more instructions per pair
-// pick the largest utilisation x efficiency.
+// How one wave is organised for A agents.  Both organisations run at the vector-ALU issue rate on a GPU-filling grid, so
+// the plan compares the VALU instructions they issue per sample and step (tools/k2_isa.sh: 90 per row and 225 in the
+// per-agent pass of the register form, 85 per 64-pair iteration and 215 per 64-agent pass of the flat form):
+//   reg  NS=1 : G = floor(64/A) samples per wave: (rows * 90 + 225) / G with rows = floor(A/2) half-ring rows
+//   reg  NS=2 : one sample, two slots per lane (64 < A <= 128): rows * 180 + 450, times 0.9 (measured: it only wins at
+//               A = 128, where the flat form's planes jump to the 208-double capacity)
+//   flat      : one sample: (ceil(P/64) * 85 + ceil(A/64) * 215) * 1.03 with P = A (A-1) / 2 pairs (its four atomics per pair)
+// Measured over the crowd size on a 128 x 128 grid (tools/form_crossover.py, profiles/r03_form_crossover.txt): the model
+// names the faster form for every A tested: register form for A <= 21 (three or more samples
+// per wave: 20-60 % faster), either for 22 <= A <= 32 (two samples per wave, within +-6 %), flat from A = 33 on (15-30 %
+// faster than one sample on 52-100 % of the lanes).  Round 2's rule (lanes used >= 0.82 x the flat form's fill) chose
+// the register form for 55 <= A <= 64 and 111 <= A <= 127, where it is 2-11 % slower.
 //   few samples (T <= 4096): flat, one sample per wave — the GPU is not full, so the
 //   shorter per-step critical path (P/64 iterations instead of A/2 rows) wins
 //   (A = 21: K2 0.10 ms vs 0.17 ms at 45..1024 samples, crossover ~4096).
@@ -1874,23 +1884,24 @@ struct wave_plan { int G; int ns; bool flat; };
 // form: SFW_K2_AUTO, or SFW_K2_REGISTER / SFW_K2_FLAT forced by the caller (sfw_set_k2_form, SFW_FORCE_FLAT in the
 // environment of sfw_create) — honoured wherever the form exists for A (register: 1 <= A <= 128; flat: A >= 2 or O > 0).
 static wave_plan plan_for(int A, int64_t T, int O, int form) {
-  wave_plan best{1, 0, true};
   if (A <= 0) return wave_plan{1, 1, false};
   const int P = A * (A - 1) / 2;
-  double best_score = P > 0 ? 0.82 * P / (64.0 * ((P + WAVE - 1) / WAVE)) : 0.0;
-  if (A <= WAVE) {
-    const int g = WAVE / A < 32 ? WAVE / A : 32;  // <= 32 samples per wave: two lanes per sample fetch its robot record
-    const double sc = 1.0 * g * A / WAVE;
-    if (sc >= best_score) { best_score = sc; best = wave_plan{g, 1, false}; }
+  const int rows = A / 2;
+  const wave_plan flat{1, 0, true};
+  const wave_plan reg = (A <= WAVE) ? wave_plan{WAVE / A < 32 ? WAVE / A : 32, 1, false} : wave_plan{1, 2, false};
+  wave_plan best = flat;
+  if (P == 0) {
+    best = reg;  // a robot alone: nothing to flatten
   } else if (A <= 2 * WAVE) {
-    const double sc = 0.95 * A / (2.0 * WAVE);
-    if (sc >= best_score) { best_score = sc; best = wave_plan{1, 2, false}; }
+    const double c_flat = 1.03 * (85.0 * ((P + WAVE - 1) / WAVE) + 215.0 * ((A + WAVE - 1) / WAVE));
+    const double c_reg = (A <= WAVE) ? (90.0 * rows + 225.0) / reg.G : 0.9 * (180.0 * rows + 450.0);
+    if (c_reg < c_flat) best = reg;
   }
   // ... and a robot alone among laser points: the flat form spreads the points over eight lanes
   // (4096: re-measured in round 3 at cfg2's prefix levels, 2240 / 6072 / 10948 classes: flat up to 6500 items K2 +3 %, up to 11000 +9 %)
-  if (T <= 4096 && (A >= 2 || O > 0)) best = wave_plan{1, 0, true};
-  if (form == SFW_K2_FLAT && (A >= 2 || O > 0)) best = wave_plan{1, 0, true};
-  if (form == SFW_K2_REGISTER && A <= 2 * WAVE) best = (A <= WAVE) ? wave_plan{WAVE / A < 32 ? WAVE / A : 32, 1, false} : wave_plan{1, 2, false};
+  if (T <= 4096 && (A >= 2 || O > 0)) best = flat;
+  if (form == SFW_K2_FLAT && (A >= 2 || O > 0)) best = flat;
+  if (form == SFW_K2_REGISTER && A <= 2 * WAVE) best = reg;
   return best;
 }
 
@@ -1960,7 +1971,8 @@ int64_t sfw_pair_table_entries(int A) {
 
 hipError_t sfw_launch_pair_table(uint16_t *tab, int A, hipStream_t stream) {
   const int n = static_cast<int>(sfw_pair_table_entries(A) / 2);
-  hipLaunchKernelGGL(sfw_pair_table_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tab, A, n);
+  const int cap = flat_cap(A) > 0 ? flat_cap(A) : flat_cap_runtime(A);  // the capacity the flat kernel will run with
+  hipLaunchKernelGGL(sfw_pair_table_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tab, A, n, cap - A);
   return hipGetLastError();
 }
 
