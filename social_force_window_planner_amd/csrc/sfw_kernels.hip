@@ -1875,9 +1875,12 @@ __global__ void __launch_bounds__(64) sfw_key_table_kernel(const sfw_sel *sel, d
 // per wave: 20-60 % faster), either for 22 <= A <= 32 (two samples per wave, within +-6 %), flat from A = 33 on (15-30 %
 // faster than one sample on 52-100 % of the lanes).  Round 2's rule (lanes used >= 0.82 x the flat form's fill) chose
 // the register form for 55 <= A <= 64 and 111 <= A <= 127, where it is 2-11 % slower.
-//   few samples (T <= 4096): flat, one sample per wave — the GPU is not full, so the
-//   shorter per-step critical path (P/64 iterations instead of A/2 rows) wins
-//   (A = 21: K2 0.10 ms vs 0.17 ms at 45..1024 samples, crossover ~4096).
+//   few items (T <= 4096; 3072 for crowds of up to 12 agents, 1536 for up to 8): flat, one sample per wave — the GPU is
+//   not full, so the shorter per-step critical path (P/64 iterations instead of A/2 rows) wins (A = 21: K2 0.10 ms vs
+//   0.15 ms at 512 items).  Measured over the item count for A = 6, 11, 21, 31 with and without the shared prefix
+//   (tools/form_vs_items.py, profiles/r03_form_crossover.txt): the flat form wins by 25-35 % up to 1024 items; small crowds
+//   (many samples per register-form wave) turn early — A = 6 from 2048 items on (11 %, 41 % at 4096), A = 11 from 4096
+//   (19 %) — while 21 and 31 agents stay within +-9 % of each other between 3072 and 5120 items.
 // All organisations produce bit-identical costs (tools/kernel_equiv.py), so the choice
 // never shows in the results.
 struct wave_plan { int G; int ns; bool flat; };
@@ -1898,8 +1901,7 @@ static wave_plan plan_for(int A, int64_t T, int O, int form) {
     if (c_reg < c_flat) best = reg;
   }
   // ... and a robot alone among laser points: the flat form spreads the points over eight lanes
-  // (4096: re-measured in round 3 at cfg2's prefix levels, 2240 / 6072 / 10948 classes: flat up to 6500 items K2 +3 %, up to 11000 +9 %)
-  if (T <= 4096 && (A >= 2 || O > 0)) best = flat;
+  if (T <= (A <= 8 ? 1536 : A <= 12 ? 3072 : 4096) && (A >= 2 || O > 0)) best = flat;
   if (form == SFW_K2_FLAT && (A >= 2 || O > 0)) best = flat;
   if (form == SFW_K2_REGISTER && A <= 2 * WAVE) best = reg;
   return best;

@@ -3,7 +3,7 @@
 K2 has two organisations of a wave — register-resident agent slots (`sfw_social_kernel<R, NS, GROUPS>`, NS = 1 for
 A <= 64 with floor(64/A) samples per wave, NS = 2 for 64 < A <= 128) and all pairs flattened over the lanes
 (`sfw_social_kernel_flat<R, GROUPS, CAP>`) — and the launcher picks one per launch by agent and item count: a grid
-of at most 4096 samples always runs flat.  The small grids the oracle can follow therefore never reached the
+of at most 4096 samples (fewer for crowds of up to 12 agents) always runs flat.  The small grids the oracle can follow therefore never reached the
 register-resident family unless it was forced.  Here every scene is scored under sfw_set_k2_form(SFW_K2_REGISTER) AND
 sfw_set_k2_form(SFW_K2_FLAT), the organisation that really ran is read back from sfw_grid_plan_info, and both are
 held to the oracle (f64: 1e-9, f32 forces: the north-star 1e-4) — not merely to each other.
