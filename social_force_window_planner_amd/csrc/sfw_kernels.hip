@@ -623,14 +623,27 @@ __device__ __forceinline__ void desired_force(const agent_consts &k, double px, 
 // reference's own 5 x 9 grid with a few people and 60..240 laser points — otherwise runs the whole O-point
 // loop on the few lanes that own an agent).
 constexpr int OBS_SEG = 8;
-template <typename R>
-__device__ __forceinline__ void obstacle_segment(const sfm_consts<R> &k, const double2 *obs, int o_begin, int o_end,
+constexpr int OBS_LANES_MAX_A = 48;  // flat form: up to this many agents the laser-point pass gives every agent eight lanes
+// The points a WAVE-UNIFORM loop reads come straight from global memory through the scalar cache (obs_global: the array
+// as a constant-address-space pointer, so that the loads are s_load and cost neither LDS space nor VALU/VMEM issue);
+// only the flat form's eight-lanes-per-agent pass, whose lanes walk eight different segments, reads them from LDS.
+// Staged in LDS for every form (16 B per point and wave), a 720-point laser scan took the flat form of the target crowd from
+// five waves per SIMD to two and the register form of cfg2 from six to three: 29 % / 27 % more time per point than at 64.
+typedef const __attribute__((address_space(4))) double *obs_global_ptr;
+__device__ __forceinline__ obs_global_ptr obs_global(const double *obstacles) {
+  return (obs_global_ptr)(const __attribute__((address_space(1))) double *)obstacles;
+}
+__device__ __forceinline__ double2 obs_point(const double2 *obs, int o) { return obs[o]; }
+__device__ __forceinline__ double2 obs_point(obs_global_ptr obs, int o) { return double2{obs[2 * o], obs[2 * o + 1]}; }
+template <typename R, typename ObsPtr>
+__device__ __forceinline__ void obstacle_segment(const sfm_consts<R> &k, ObsPtr obs, int o_begin, int o_end,
                                                  double px, double py, R c0, R neg_inv_sigma, R &ax, R &ay) {
   using namespace sfwm;
   ax = R(0);
   ay = R(0);
+#pragma unroll 4
   for (int o = o_begin; o < o_end; ++o) {
-    const double2 q = obs[o];
+    const double2 q = obs_point(obs, o);
     const R mx = R(px - q.x), my = R(py - q.y);
     R rm, mn;
     rsqrt_sqrt(fma(mx, mx, fma(my, my, tiny_of<R>::v)), rm, mn);
@@ -644,8 +657,8 @@ template <typename R> __device__ __forceinline__ R obstacle_c0(const agent_const
   return static_cast<R>(fma(radius, c.inv_sigma, c.ln_f_obstacle));
 }
 // all eight segments on one lane
-template <typename R>
-__device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const agent_consts &c, const double2 *obs,
+template <typename R, typename ObsPtr>
+__device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const agent_consts &c, ObsPtr obs,
                                                double px, double py, double radius, double &fx, double &fy) {
   const int O = c.O, L = (O + OBS_SEG - 1) / OBS_SEG;
   const R c0 = obstacle_c0<R>(c, radius), nis = static_cast<R>(-c.inv_sigma);
@@ -653,7 +666,7 @@ __device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const age
   for (int seg = 0; seg < OBS_SEG; ++seg) {
     const int b = seg * L, e = min(b + L, O);
     R ax, ay;
-    obstacle_segment<R>(k, obs, b, e, px, py, c0, nis, ax, ay);
+    obstacle_segment<R, ObsPtr>(k, obs, b, e, px, py, c0, nis, ax, ay);
     tx = seg == 0 ? ax : tx + ax;
     ty = seg == 0 ? ay : ty + ay;
   }
@@ -709,7 +722,7 @@ struct lds_layout {
     if (with_frc) {  // flat kernel
       fcx = reinterpret_cast<double *>(take(plane));
       fcy = reinterpret_cast<double *>(take(plane));
-      obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? O : 1)));
+      obs = (O > 0 && A <= OBS_LANES_MAX_A) ? reinterpret_cast<double2 *>(take(sizeof(double2) * O)) : nullptr;  // eight-lanes pass only
       rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * 2));
       swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
       opart = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? 64 : 0)));
@@ -728,7 +741,7 @@ struct lds_layout {
       swp = reinterpret_cast<double *>(take(plane));
       dead = reinterpret_cast<int *>(take(sizeof(int) * REG_DEAD_CAP));
       rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * G));
-      obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? O : 1)));
+      obs = nullptr;  // every loop over the laser points is wave-uniform here: scalar loads from global memory
     }
     ac = reinterpret_cast<sfw_agent_const *>(take(sizeof(sfw_agent_const) * (consts ? A : 0)));
     // group arrays only when an agent carries a group id (the GROUPS kernels): nothing reads them otherwise
@@ -937,7 +950,8 @@ __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout
       s.ac[i] = L.agent_c[i];
     }
   }
-  for (int o = lane; o < O; o += WAVE) s.obs[o] = double2{L.obstacles[2 * o], L.obstacles[2 * o + 1]};
+  if (s.obs)
+    for (int o = lane; o < O; o += WAVE) s.obs[o] = double2{L.obstacles[2 * o], L.obstacles[2 * o + 1]};
   if constexpr (GROUPS) {
     for (int i = lane; i < A; i += WAVE) s.grp[i] = L.agent_grp[i];
     for (int q = lane; q <= L.NG; q += WAVE) s.goff[q] = L.grp_off[q];
@@ -1103,6 +1117,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
       io_[r] = 8u * static_cast<uint32_t>(slc);
       ci_[r] = ac_off + static_cast<uint32_t>(sizeof(sfw_agent_const)) * static_cast<uint32_t>(i_[r]);
       g4_[r] = 4u * static_cast<uint32_t>(g_[r]);
+      asm("" : "+v"(g4_[r]));  // opaque: the epilogue's g4 >> 2 must not resurrect g_ (kept in scratch across the rollout otherwise)
       const int i = i_[r];
       fx[r] = fy[r] = sw[r] = 0.0;
       // the slot's Wp switch: a person whose id is not the robot's receives the robot-on-person term (ref :692)
@@ -1140,7 +1155,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
           desired_force(c0, px, py, vx, vy, hg != 0, ak.gx, ak.gy, ak.gr, ak.dv, fx[r], fy[r]);
           if (O > 0) {
             double ox, oy;
-            obstacle_force<R>(k0, c0, s.obs, px, py, ak.rad, ox, oy);
+            obstacle_force<R>(k0, c0, obs_global(L.obstacles), px, py, ak.rad, ox, oy);
             fx[r] += ox;
             fy[r] += oy;
           }
@@ -1335,7 +1350,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         if (ok_[r] && lds_at<int>(smem, off::DEAD + g4_[r]) == 0) {
           const uint32_t io = io_[r];
           double ox, oy;
-          obstacle_force<R>(k, c, s.obs, lds_at<double>(smem, io), lds_at<double>(smem, io + PY),
+          obstacle_force<R>(k, c, obs_global(late_args()->obstacles), lds_at<double>(smem, io), lds_at<double>(smem, io + PY),
                             lds_at<double>(smem, ci_[r] + 32u), ox, oy);
           if (i_[r] == 0) {
             sw[r] += lds_at<double>(smem, io + off::SW) + fast_norm(ox, oy);
@@ -1504,7 +1519,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
         desired_force(c0, px, py, vx, vy, c.has_goal != 0, c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity, fx, fy);
         if (O > 0) {
           double ox, oy;
-          obstacle_force<R>(k, c0, s.obs, px, py, c.radius, ox, oy);
+          obstacle_force<R>(k, c0, obs_global(L.obstacles), px, py, c.radius, ox, oy);
           fx += ox;
           fy += oy;
         }
@@ -1640,10 +1655,14 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     const sfw_robot_step rs = s.rsb[step & 1];
     if (step + 1 < step_end) fetch_robot(La->rstep, La->rstep_stride, step + 1, (step + 1) & 1);
     const bool with_obs = c.O > 0;
+    // the lane index, opaque once per step: the 64-bit byte offset of the lane's agent constants (48 * lane) is then formed
+    // here (two instructions) instead of being held — in scratch, for the 104- and 208-double capacities — across the pair loop
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
 #if defined(SFW_ABL_NOAGENT)
-    for (int sl = lane; sl < 0; sl += WAVE) {
+    for (int sl = lane_s; sl < 0; sl += WAVE) {
 #else
-    for (int sl = lane; sl < A; sl += WAVE) {
+    for (int sl = lane_s; sl < A; sl += WAVE) {
 #endif
       const agent_k ak = GROUPS ? agent_k_lds(s, sl) : agent_k_global(agent_c, sl);
       double px = s.px[sl], py = s.py[sl], vx = s.vx[sl], vy = s.vy[sl];
@@ -1692,7 +1711,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
           s.fcy[a] += oy;
         }
       };
-      if (A <= 48) {
+      if (A <= OBS_LANES_MAX_A) {
         const int L8 = (c.O + OBS_SEG - 1) / OBS_SEG, seg = lane & (OBS_SEG - 1);
         const int ob = seg * L8, oe = min(ob + L8, c.O);
         const R nis = static_cast<R>(-c.inv_sigma);
@@ -1701,7 +1720,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
           R ax = R(0), ay = R(0);
           if (a < A) {
             const double rad = GROUPS ? s.ac[a].radius : agent_c[a].radius;
-            obstacle_segment<R>(k, s.obs, ob, oe, s.px[a], s.py[a], obstacle_c0<R>(c, rad), nis, ax, ay);
+            obstacle_segment<R, const double2 *>(k, s.obs, ob, oe, s.px[a], s.py[a], obstacle_c0<R>(c, rad), nis, ax, ay);
           }
           s.opart[lane] = double2{static_cast<double>(ax), static_cast<double>(ay)};
           __syncthreads();
@@ -1720,7 +1739,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
         for (int a = lane; a < A; a += WAVE) {
           const double rad = GROUPS ? s.ac[a].radius : agent_c[a].radius;
           double ox, oy;
-          obstacle_force<R>(k, c, s.obs, s.px[a], s.py[a], rad, ox, oy);
+          obstacle_force<R>(k, c, obs_global(La->obstacles), s.px[a], s.py[a], rad, ox, oy);
           apply(a, ox, oy);
         }
         __syncthreads();
