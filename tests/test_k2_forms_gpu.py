@@ -113,11 +113,12 @@ def test_relative_rest(oracle_mod, hip_mod, n_people, robot_moving, form, prec, 
     _check(oracle_mod, hip_mod, scene, form, prec, rtol, rs=rs)
 
 
-# (d) laser points: O = 64 at A = 21 (BASELINE-adjacent `cfg2_o64`), O = 7 with groups, O = 1, O = 240 with two slots
+# (d) laser points: O = 64 at A = 21 (BASELINE-adjacent `cfg2_o64`), O = 7 with groups, O = 1, O = 240 with two slots, a whole
+#     720-point scan (scalar-cache loads in the wave-uniform loops, the LDS copy in the eight-lanes pass)
 @pytest.mark.parametrize("prec,rtol", PRECISIONS)
 @pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("n_people,n_obs,grouped,seed", [(20, 64, False, 0), (20, 7, True, 60), (59, 7, True, 99), (20, 1, False, 0),
-                                                         (99, 240, False, 0), (99, 33, True, 43), (99, 33, True, 56), (0, 16, False, 0)])
+                                                         (99, 240, False, 0), (20, 720, False, 0), (50, 720, False, 0), (99, 33, True, 43), (99, 33, True, 56), (0, 16, False, 0)])
 def test_laser_points(oracle_mod, hip_mod, n_people, n_obs, grouped, seed, form, prec, rtol):
     if grouped:  # seeds 43 / 56: a third of the samples end in a pedestrian contact
         scene = _grouped_scene(n_people, seed, n_obstacles=n_obs)
