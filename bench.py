@@ -26,6 +26,7 @@ from __future__ import annotations
 import argparse
 import dataclasses
 import json
+import math
 import os
 import sys
 import time
@@ -53,7 +54,7 @@ def parse_args():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads under `extra`")
-    ap.add_argument("--extras", default="cfg5_strong,inproc_multi,upload,resident,cfg2,cfg2_o64,cfg3,cfg4,f32",
+    ap.add_argument("--extras", default="cfg5_strong,target_strong,inproc_multi,upload,resident,cfg2,cfg2_o64,cfg2_o240,target_o720,cfg3,cfg4,f32",
                     help="comma-separated secondary measurements to run (all by default)")
     ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each secondary workload")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -64,7 +65,12 @@ def parse_args():
     ap.add_argument("--inproc-timeout", type=float, default=420.0,
                     help="N > 1: wall-clock limit of each one-process multi-device measurement (run in a child process)")
     ap.add_argument("--grid", default=None, help="override the sample grid, e.g. 512x512 (experiments only)")
-    ap.add_argument("--verify", action="store_true", help="check the GPU result against the oracle on a sample subset")
+    ap.add_argument("--verify", action="store_true", help=argparse.SUPPRESS)  # the default since round 4 (kept for old command lines)
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the oracle check of the headline launch (outside the timed region; on by default)")
+    ap.add_argument("--verify-budget", type=float, default=75.0,
+                    help="seconds of all-core oracle time the verify leg may take: the WHOLE grid when it fits (the target "
+                         "grid: ~30 s on the 256-thread GPU box), else a sub-grid spread over the whole grid")
     ap.add_argument("--resident", action="store_true",
                     help="time launch + selection fetch only (no stage, no cost-vector D2H): kernel tuning aid")
     return ap.parse_args()
@@ -124,6 +130,70 @@ def cpu_baseline(scene, params_kw, budget_s=12.0):
         "cpu_model": cpu_model,
         "nproc": os.cpu_count(),
     }
+
+
+def verify_against_oracle(job, costs, best, budget_s, global_key=None):
+    """The launch bench.py times, checked against the CPU oracle OUTSIDE the timed region: the whole grid of this rank when
+    the oracle finishes it within budget_s on all host threads, otherwise a sub-grid spread evenly over the whole grid.
+    Compared: sentinel sets (-1 rejected, -2 the never-scored (0,0) sample), every valid cost (max relative error), and —
+    whole grid only — the selection: index, vx, vtheta, n_valid (ref src/sfw_planner.cpp:394-414)."""
+    from oracle.sfw_oracle import OracleScorer
+    from social_force_window_planner_amd._abi import default_params
+
+    o = OracleScorer(default_params(**job.params_kw))
+    o.load_scene(job.scene)
+    rs, ga, lin, ang = job.scene.robot_state, job.scene.goal_args, job.lin, job.ang
+    cores = os.cpu_count() or 1
+    grid = np.asarray(costs).reshape(len(lin), len(ang))
+    # calibrate the all-core oracle on a few samples spread over the grid
+    cr = np.unique(np.linspace(0, len(lin) - 1, 4).round().astype(int))
+    cc = np.unique(np.linspace(0, len(ang) - 1, min(len(ang), max(16, cores // 2))).round().astype(int))
+    t0 = time.perf_counter()
+    o.score_grid(rs, lin[cr], ang[cc], ga, n_threads=cores)
+    per = (time.perf_counter() - t0) / (len(cr) * len(cc))
+    n_fit = int(budget_s / max(per, 1e-9))
+    whole = n_fit >= len(lin) * len(ang)
+    if whole:
+        rows, cols = np.arange(len(lin)), np.arange(len(ang))
+    else:
+        side = max(2, int(math.sqrt(n_fit)))
+        rows = np.unique(np.linspace(0, len(lin) - 1, min(len(lin), side)).round().astype(int))
+        cols = np.unique(np.linspace(0, len(ang) - 1, min(len(ang), max(2, n_fit // len(rows)))).round().astype(int))
+    t0 = time.perf_counter()
+    oc, ob = o.score_grid(rs, lin[rows], ang[cols], ga, n_threads=cores)
+    t_or = time.perf_counter() - t0
+    gc = grid[np.ix_(rows, cols)].ravel()
+    v = oc >= 0
+    same_set = bool(np.array_equal(oc < 0, gc < 0) and np.array_equal(oc[oc < 0], gc[gc < 0]))
+    rel = np.abs(gc[v] - oc[v]) / np.abs(oc[v]) if v.any() else np.zeros(1)
+    out = {
+        "samples": int(len(oc)),
+        "coverage": ("the whole grid the timed launch scored" if whole else
+                     f"{len(rows)} x {len(cols)} sub-grid spread over the whole grid, out of the full-size launch's cost vector"),
+        "max_rel_err": float(rel.max()),
+        "median_rel_err": float(np.median(rel)),
+        "invalid_set_equal": same_set,
+        "n_valid_oracle": int(v.sum()),
+        "cmd_vel_match": None,
+        "oracle": {"threads": cores, "seconds": t_or, "trajectories_per_s": len(oc) / t_or},
+        "tolerance": "f64 parity mode: tests assert 1e-9 relative; north star asks 1e-4 and an identical cmd_vel",
+    }
+    if whole:
+        # GridJob stages this rank's rows with index_base = row0 * nw; the oracle's index is local to the rows it was given
+        out["cmd_vel_match"] = bool(best["index"] - job.index_base == ob["index"] and best["vx"] == ob["vx"]
+                                    and best["vtheta"] == ob["vtheta"] and best["n_valid"] == ob["n_valid"])
+        out["oracle_cmd_vel"] = {"vx": ob["vx"], "vtheta": ob["vtheta"], "cost": ob["cost"], "index": ob["index"] + job.index_base,
+                                 "n_valid": ob["n_valid"]}
+    if not whole or global_key:
+        # the selected sample itself, wherever it lies: its cost under the oracle, and that no checked sample beats it
+        gi = int(-global_key[3]) if global_key else best["index"]
+        if gi >= 0:
+            r, c = divmod(gi, len(ang))
+            c1, _ = o.score_grid(rs, job.lin_all[r:r + 1], ang[c:c + 1], ga, n_threads=1)
+            gcost = global_key[0] if global_key else best["cost"]
+            out["selected_sample"] = {"index": gi, "oracle_cost": float(c1[0]), "rel_err": float(abs(c1[0] - gcost) / abs(c1[0])),
+                                      "no_sampled_cost_below_it": bool(not v.any() or oc[v].min() >= c1[0] * (1 - 1e-9))}
+    return out
 
 
 class GridJob:
@@ -235,17 +305,19 @@ def run_config(workload_name, precision, steps, warmup, ctx, scaling="weak", res
         tot = torch.tensor([float(job.n_scored)], dtype=torch.float64, device=cd)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         n_scored_total = int(tot.item())
-        mine = torch.zeros((world, 6), dtype=torch.float64, device=cd)
+        mine = torch.zeros((world, 7), dtype=torch.float64, device=cd)
         mine[rank] = torch.tensor([float(np.mean(k2_ms)), float(np.median(wall)) * 1e3,
                                    float(np.median(state["xchg"])) * 1e6, executed_share_of(job),
-                                   job.scorer.sustained_clock_ghz(), float(len(job.lin))], dtype=torch.float64)
+                                   job.scorer.sustained_clock_ghz(), float(len(job.lin)), float(job.plan["levels"])],
+                                  dtype=torch.float64)
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)
         tab = mine.cpu().numpy()
         # executed_share differs per rank: every block of rows spans another velocity range, so its shared-prefix tree
         # saves another share of the steps — K2 time per rank follows it (read the imbalance here, not as "efficiency")
         per_rank = {"social_kernel_ms": tab[:, 0].tolist(), "median_step_ms": tab[:, 1].tolist(),
                     "exchange_us": tab[:, 2].tolist(), "executed_share": tab[:, 3].tolist(),
-                    "sustained_clock_ghz": tab[:, 4].tolist(), "rows": [int(v) for v in tab[:, 5]]}
+                    "sustained_clock_ghz": tab[:, 4].tolist(), "rows": [int(v) for v in tab[:, 5]],
+                    "levels": [int(v) for v in tab[:, 6]]}
         win_rank, win_key = state["win"]
     else:
         n_scored_total = job.n_scored
@@ -301,6 +373,9 @@ def inproc_multi(workload_name, precision, devices, exchange, steps, warmup):
             "exchange_us": float(np.median([u["exchange_us"] for u in us])),
             "fetch_us": float(np.median([u["fetch_us"] for u in us])),
             "levels_rank0": plan_info_of_rank(m, 0)["levels"],
+            "levels": [plan_info_of_rank(m, r)["levels"] for r in range(len(devices))],
+            "rows": [m.rank_rows(r)[1] for r in range(len(devices))],
+            "collective": m.describe(),  # communicators ncclCommInitAll returned, their size and devices, RCCL version
             "cmd_vel_index": best["index"],
         }
     finally:
@@ -328,6 +403,29 @@ def inproc_multi_guarded(workload_name, precision, devices, exchange, steps, war
         if line.startswith("{"):
             return json.loads(line)
     return {"error": f"child exit {out.returncode}: {out.stderr.strip()[-400:]}"}
+
+
+def collective_info(dist, backend, ctx):
+    """What the process group behind the per-step all-reduce(min) really is (a SCALE record must say what it measured)."""
+    import torch
+
+    info = {"backend": dist.get_backend(), "requested_backend": backend, "world_size": dist.get_world_size(),
+            "rank_devices": None, "rccl_version": None, "visible_devices": torch.cuda.device_count(),
+            "op": "all_reduce(MIN) of the [N,4] f64 key table, once per step", "coll_device": ctx["coll_device"]}
+    try:
+        v = torch.cuda.nccl.version()  # RCCL's version on ROCm
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:  # noqa: BLE001
+        info["rccl_version"] = f"unavailable ({type(e).__name__})"
+    try:
+        devs = [None] * dist.get_world_size()
+        dist.all_gather_object(devs, {"rank": ctx["rank"], "device": ctx["device"],
+                                      "name": torch.cuda.get_device_name(ctx["device"]),
+                                      "hip_visible": os.environ.get("HIP_VISIBLE_DEVICES")})
+        info["rank_devices"] = devs
+    except Exception as e:  # noqa: BLE001
+        info["rank_devices"] = f"unavailable ({type(e).__name__}: {e})"
+    return info
 
 
 def host_wait(dist, rank, key):
@@ -419,7 +517,9 @@ def roofline_for(job, k2_ms, precision, brief=False):
 def workload_text(w):
     return (f"{w.name}: {w.nv}x{w.nw} (v,w) grid, {w.n_people} pedestrians, {w.map_size}x{w.map_size} costmap, "
             f"sim_time={w.sim_time} s, sim_granularity={w.sim_granularity} ({w.n_steps} steps), 16-gon footprint"
-            + (f", {w.n_obstacles} laser points" if w.n_obstacles else ""))
+            + (f", {w.n_obstacles} laser points" if w.n_obstacles else "")
+            + (", pedestrians from 2.1 m (NOT SURVEY §8d's 0.8 m, where every sample of this crowd ends in a contact: "
+               "tests/test_parity_gpu.py::test_cfg4_spec_crowd_full_size)" if w.n_people >= 150 and w.people_r_in is None else ""))
 
 
 def extra_entry(name, precision, steps, warmup, ctx):
@@ -531,6 +631,14 @@ def main():
                                  "cost": res["global_key"][0] if res["global_key"] else -1.0,
                                  "winner_rank": res["winner_rank"]}
         out["per_rank"] = res["per_rank"]
+        out["collective"] = collective_info(dist, args.backend, ctx)
+        if not args.no_verify:
+            if rank == 0:  # rank 0's own row block against the oracle + the globally selected sample, outside the timed region
+                costs, vbest, _ = job.step()
+                out["verify"] = verify_against_oracle(job, costs, vbest, min(args.verify_budget, 45.0), global_key=res["global_key"])
+                out["verify"]["scope"] = f"rank 0's rows [{job.row0}, {job.row0 + len(job.lin)}) of {w.nv}"
+                del costs
+            host_wait(dist, rank, "sfw_verify_done")
     extra = {}
     wanted = set() if (args.no_extra or args.resident) else set(args.extras.split(","))
     if "cfg5_strong" in wanted:
@@ -553,6 +661,18 @@ def main():
             "roofline_frac_rank0": roofline_for(j5, r5["k2_ms"], args.precision, brief=True),
         }
         del j5, r5
+    if "target_strong" in wanted and world > 1:
+        # The headline grid itself cut over the N ranks (strong scaling of a target-sized grid): every rank's block shares
+        # less of its prefix (per_rank.levels / executed_share), so this curve is sub-linear by construction — shown as a number
+        rt = run_config(args.workload, args.precision, max(5, args.extra_steps), 2, ctx, scaling="strong")
+        jt = rt["job"]
+        extra["target_strong"] = {
+            "workload": workload_text(jt.workload) + f", rows sharded over {world} GPU(s)",
+            "value": rt["n_scored_total"] * rt["steps"] / rt["elapsed"], "unit": "trajectories/s", "steps": rt["steps"],
+            "ms_per_step": rt["elapsed"] / rt["steps"] * 1e3, "n_gpus": world, "scaling": "strong",
+            "samples_per_gpu": jt.n_local, "per_rank": rt["per_rank"],
+        }
+        del jt, rt
     if "inproc_multi" in wanted and world > 1:
         # The plugin-shaped path at N > 1: rank 0 ALONE drives all N devices from one process through
         # sfw_multi_score_grid over SFW_MULTI_RCCL (ncclCommInitAll + one grouped ncclAllReduce(min) per call); the other
@@ -571,20 +691,12 @@ def main():
         host_wait(dist, rank, "sfw_inproc_multi_done")
     if rank == 0 and world == 1 and not args.resident:
         job = GridJob(args.workload, args.precision, 0, 1, local_rank)
-        if args.verify:
-            from oracle.sfw_oracle import OracleScorer
-            from social_force_window_planner_amd._abi import default_params
-
-            o = OracleScorer(default_params(**job.params_kw))
-            o.load_scene(job.scene)
-            costs, best, _ = job.step()
-            rows = np.unique(np.linspace(0, len(job.lin) - 1, 4).round().astype(int))
-            oc, _ = o.score_grid(job.scene.robot_state, job.lin[rows], job.ang, job.scene.goal_args,
-                                 n_threads=os.cpu_count())
-            gc = costs.reshape(len(job.lin), len(job.ang))[rows].ravel()
-            v = oc >= 0
-            out["verify"] = {"max_rel_err": float((np.abs(gc[v] - oc[v]) / np.abs(oc[v])).max()),
-                             "same_invalid_set": bool(np.array_equal(oc < 0, gc < 0)), "rows": len(rows)}
+        if not args.no_verify:
+            # the oracle on the headline grid itself, outside the timed region (the metric says "cmd_vel match")
+            costs, vbest, _ = job.step()
+            out["verify"] = verify_against_oracle(job, costs, vbest, args.verify_budget)
+            out["verify"]["same_cmd_vel_as_timed_steps"] = vbest["index"] == out["cmd_vel"]["index"]
+            del costs
         if "inproc_multi" in wanted:
             # sfw_multi_score_grid on the one visible device: R host-reduce ranks sharing it (row blocks, worker thread per
             # rank, column plan shared).  What scales here is the HOST side: the enqueue phase must not grow with R.
@@ -605,13 +717,17 @@ def main():
                 job.scorer.load_scene(job.scene)
             job.scorer.sync()
             extra["world_upload_ms"] = (time.perf_counter() - t0) / reps * 1e3  # costmap + footprint + agents H2D
+            # SURVEY §8d's metric counts the H2D of the inputs: the headline with the per-cycle world upload added to every step
+            out["value_incl_world_upload"] = job.n_scored / ((out["ms_per_step"] + extra["world_upload_ms"]) * 1e-3)
+            out["config"]["world_state"] = ("resident: costmap + footprint + agents are uploaded before the timed region "
+                                            "(extra.world_upload_ms per cycle; value_incl_world_upload adds it to every step)")
         if "resident" in wanted:
             r_res = run_config(args.workload, args.precision, max(5, args.steps // 2), 2, ctx, resident=True)
             extra["resident_launch"] = {
                 "value": r_res["n_scored_total"] * r_res["steps"] / r_res["elapsed"], "unit": "trajectories/s",
                 "ms_per_step": r_res["elapsed"] / r_res["steps"] * 1e3,
                 "note": "launch + 48-byte selection fetch only, grid staged once (round-1 headline form)"}
-        for name in ("cfg2", "cfg2_o64", "cfg3", "cfg4"):
+        for name in ("cfg2", "cfg2_o64", "cfg2_o240", "target_o720", "cfg3", "cfg4"):
             if name in wanted and name != args.workload:
                 extra[name] = extra_entry(name, args.precision, args.extra_steps, 2, ctx)
         if "f32" in wanted:

@@ -110,13 +110,16 @@ typedef struct sfw_agent {
                               twist, as in sensor_interface.cpp:566-575     */
   double goal_x, goal_y;   /* goals.front().center (ignored if !has_goal)   */
   double goal_radius;      /* goals.front().radius                          */
-  double desired_velocity; /* Agent::desiredVelocity; must be > 0 for a person
-                              (index >= 1): one that can never move would be
-                              at exact relative rest with its like at every
-                              step, where the reference's interaction angle
-                              is libm rounding noise (only the handed-over
-                              state's such pairs are reproduced, DESIGN.md
-                              §5) -> SFW_ERR_UNSUPPORTED                    */
+  double desired_velocity; /* Agent::desiredVelocity.  <= 0 is accepted, as
+                              the reference accepts people_velocity_ = 0
+                              (sensor_interface.cpp:503): the speed clamp of
+                              updatePosition pins such a person where it
+                              stands.  With a stopped robot (or its like) it
+                              is at exact relative rest at EVERY step; the
+                              angular term of such a pair is exactly 0 here
+                              where lightsfm's sign(theta) is the rounding
+                              noise of two atan2 (-1, 0 or +1): reproduced
+                              for the handed-over state only */
   double radius;           /* Agent::radius                                 */
   int32_t has_goal;        /* goals non-empty (people: 1, robot at t0: 0)   */
   int32_t id;              /* Agent::id — the robot-on-person force skips a
@@ -345,6 +348,15 @@ int sfw_multi_create(const sfw_params *params, const int *devices, int32_t R, in
 int sfw_multi_destroy(sfw_multi_handle m);
 const char *sfw_multi_last_error(sfw_multi_handle m);
 int32_t sfw_multi_ranks(sfw_multi_handle m);
+/* What the handle really runs on (diagnostics; a scaling record must say what it measured): the devices as listed, the
+ * exchange, and — SFW_MULTI_RCCL — how many communicators ncclCommInitAll returned, the size communicator 0 reports
+ * (ncclCommCount), the device every communicator reports (ncclCommCuDevice) and RCCL's version code (ncclGetVersion);
+ * -1 / 0 where the library does not export the query.  At most the first 64 ranks are listed. */
+typedef struct sfw_multi_desc {
+  int32_t ranks, exchange, communicators, comm_size, rccl_version;
+  int32_t devices[64], comm_devices[64];
+} sfw_multi_desc;
+int sfw_multi_describe(sfw_multi_handle m, sfw_multi_desc *out);
 /* Rank r's handle (owned by m): for the single-sample calls (sfw_score_one on rank 0) and diagnostics. */
 sfw_handle sfw_multi_rank_handle(sfw_multi_handle m, int32_t r);
 /* World state and parameters, replicated to every rank. */

@@ -173,6 +173,7 @@ EXPORTED_SYMBOLS = (
     "sfw_multi_create",
     "sfw_multi_destroy",
     "sfw_multi_last_error",
+    "sfw_multi_describe",
     "sfw_multi_ranks",
     "sfw_multi_rank_handle",
     "sfw_multi_set_params",

@@ -1100,11 +1100,8 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
     if (!all_finite(&a.x, 4) || !std::isfinite(a.desired_velocity) || !std::isfinite(a.radius) ||
         (a.has_goal && !(all_finite(&a.goal_x, 2) && std::isfinite(a.goal_radius))))
       return fail(h, SFW_ERR_INVALID_ARG, "set_agents: non-finite field in agent " + std::to_string(i));
-    // A person that may never move (speed clamp to 0, lightsfm updatePosition) stays at exact relative rest with every
-    // other such person — and with a stopped robot — at EVERY step, where the reference's interaction angle is libm
-    // rounding noise (see rest_forces): only the handed-over state is covered by the host-evaluated terms
-    if (i > 0 && !(a.desired_velocity > 0.0))
-      return fail(h, SFW_ERR_UNSUPPORTED, "set_agents: person " + std::to_string(i) + " has desired_velocity <= 0 (include/sfw_hip.h, sfw_agent)");
+    // desired_velocity <= 0 is accepted, as the reference accepts people_velocity_ = 0 (sensor_interface.cpp:503): the speed
+    // clamp of lightsfm's updatePosition pins such a person where it stands (include/sfw_hip.h, sfw_agent)
   }
   if (O > 0 && !all_finite(obstacles_xy, 2 * static_cast<size_t>(O)))
     return fail(h, SFW_ERR_INVALID_ARG, "set_agents: non-finite laser point");
@@ -1515,6 +1512,10 @@ struct rccl_api {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  // optional (sfw_multi_describe): what the communicators say about themselves
+  ncclResult_t (*GetVersion)(int *) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
   void load_once() {
     for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
       lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
@@ -1531,6 +1532,9 @@ struct rccl_api {
     GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
     GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    GetVersion = reinterpret_cast<decltype(GetVersion)>(sym("ncclGetVersion"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
+    CommCuDevice = reinterpret_cast<decltype(CommCuDevice)>(sym("ncclCommCuDevice"));
     if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd || !GetErrorString) {
       dlclose(lib);
       lib = nullptr;
@@ -1727,6 +1731,25 @@ int sfw_multi_destroy(sfw_multi_handle m) {
 
 const char *sfw_multi_last_error(sfw_multi_handle m) { return m ? m->err.c_str() : "null handle"; }
 int32_t sfw_multi_ranks(sfw_multi_handle m) { return m ? m->R : 0; }
+int sfw_multi_describe(sfw_multi_handle m, sfw_multi_desc *out) {
+  if (!m || !out) return SFW_ERR_INVALID_ARG;
+  std::memset(out, 0, sizeof(*out));
+  out->ranks = m->R;
+  out->exchange = m->exchange;
+  for (int r = 0; r < m->R && r < 64; ++r) out->devices[r] = m->dev[static_cast<size_t>(r)];
+  for (int r = 0; r < 64; ++r) out->comm_devices[r] = -1;
+  out->comm_size = -1;
+  if (m->exchange == SFW_MULTI_RCCL) {
+    if (g_rccl.GetVersion) (void)g_rccl.GetVersion(&out->rccl_version);
+    for (size_t r = 0; r < m->comm.size() && r < 64; ++r)
+      if (m->comm[r]) {
+        out->communicators += 1;
+        if (g_rccl.CommCuDevice) (void)g_rccl.CommCuDevice(m->comm[r], &out->comm_devices[r]);
+        if (r == 0 && g_rccl.CommCount) (void)g_rccl.CommCount(m->comm[r], &out->comm_size);
+      }
+  }
+  return SFW_OK;
+}
 sfw_handle sfw_multi_rank_handle(sfw_multi_handle m, int32_t r) {
   return (m && r >= 0 && r < m->R) ? m->h[static_cast<size_t>(r)] : nullptr;
 }

@@ -8,11 +8,14 @@
 
 #include "../../include/sfw_hip.h"
 
-// 1: the pair term's angular part takes the sign BIT of w x diff (one v_bfi_b32), also when that product is exactly zero;
-// the host-evaluated terms of such pairs (rest_forces) then include the cancellation of the kernels' own.  0: the kernels
-// keep an exact zero there (a compare and two selects per pair evaluation: round 2's form, kept for A/B).
+// 0 (default): the pair term's angular part is exactly 0 for a pair whose w x diff is exactly 0 — sign(theta) = 0, as in
+// lightsfm for theta == 0 — at every step (a compare and one integer select per pair evaluation, exp_fast2_gated); the host
+// evaluates the reference's rounding-noise term for such pairs of the handed-over state (rest_forces).
+// 1: round 3's form, kept for A/B: the sign BIT of w x diff decides also for a zero (one v_bfi_b32, 2 issue slots less per
+// pair) and rest_forces takes the kernels' own term back out — right for the handed-over state only: an alignment that
+// persists (a robot driving straight at a person on its axis) then gets a full-magnitude lateral force from step 1 on.
 #ifndef SFW_SIGN_OF_ZERO
-#define SFW_SIGN_OF_ZERO 1
+#define SFW_SIGN_OF_ZERO 0
 #endif
 
 // Per-sample status written by the rollout kernel.
@@ -43,7 +46,9 @@ struct __attribute__((aligned(16))) sfw_agent_const {
 // derived on the device (a division, a product) is a VALU result and would sit in a VGPR pair
 // of every lane for the whole rollout.
 template <typename R> struct sfw_force_k {
-  R lambda, neg_inv_gamma, ln_f_social, c_vel, c_ang, ln_f_obstacle, inv_sigma;  // c_vel = -(n' gamma)^2, c_ang = -(n gamma)^2
+  // Everything that ends up in an exponent is in LOG2 units (the device evaluates 2^x, sfw_math.h): -log2(e)/gamma,
+  // log2(Fs), c_vel = -(n' gamma)^2 log2(e), c_ang = -(n gamma)^2 log2(e), log2(k_obstacle), log2(e)/sigma
+  R lambda, neg_l2e_inv_gamma, l2_f_social, c_vel, c_ang, l2_f_obstacle, l2e_inv_sigma;
 };
 struct sfw_derived {
   sfw_force_k<double> d;

@@ -481,11 +481,11 @@ __device__ __forceinline__ void clock_probe(int which) {
 // Social-force constants of the PAIR term in the force type (host-derived, see sfw_derived).
 template <typename R> struct sfm_consts {
   sfwm::poly_consts pc;
-  R lambda, neg_inv_gamma, ln_f_social, c_vel, c_ang;
+  R lambda, neg_l2e_inv_gamma, l2_f_social, c_vel, c_ang;
 };
 // Constants of the per-agent pass (desired / obstacle / group forces, integration, contact test): read late.
 struct agent_consts {
-  double f_desired, inv_tau, dt, rr, inv_O, ln_f_obstacle, inv_sigma;
+  double f_desired, inv_tau, dt, rr, inv_O, l2_f_obstacle, l2e_inv_sigma;
   double f_gaze, f_coherence, f_repulsion;
   int O, robot_id;
 };
@@ -496,8 +496,8 @@ __device__ __forceinline__ agent_consts load_agent_consts(late_launch La, bool f
   c.dt = La->dt;
   c.rr = La->k.rr;
   c.inv_O = La->k.inv_O;
-  c.ln_f_obstacle = f32 ? static_cast<double>(La->k.f.ln_f_obstacle) : La->k.d.ln_f_obstacle;
-  c.inv_sigma = f32 ? static_cast<double>(La->k.f.inv_sigma) : La->k.d.inv_sigma;
+  c.l2_f_obstacle = f32 ? static_cast<double>(La->k.f.l2_f_obstacle) : La->k.d.l2_f_obstacle;
+  c.l2e_inv_sigma = f32 ? static_cast<double>(La->k.f.l2e_inv_sigma) : La->k.d.l2e_inv_sigma;
   c.f_gaze = La->p.sfm_force_factor_group_gaze;
   c.f_coherence = La->p.sfm_force_factor_group_coherence;
   c.f_repulsion = La->p.sfm_force_factor_group_repulsion;
@@ -520,11 +520,7 @@ __device__ __forceinline__ agent_consts load_agent_consts(late_launch La, bool f
 // cw = w x diff evaluated in double by the caller (exact sign in both modes).
 __device__ __forceinline__ double copysign_from(double mag, double sgn) { return __builtin_copysign(mag, sgn); }
 __device__ __forceinline__ float copysign_from(float mag, double sgn) {
-#if SFW_SIGN_OF_ZERO
   return __builtin_copysignf(mag, static_cast<float>(sgn));  // the conversion keeps the sign bit, of zeros and of underflows too
-#else
-  return __builtin_copysignf(mag, sgn < 0.0 ? -1.0f : 1.0f);
-#endif
 }
 
 // NORM_ONLY: fx receives |f| = sqrt(ev^2 + ea^2) (Ihat and its left normal are orthonormal) and fy nothing — what
@@ -546,17 +542,22 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   const R sn = fma(ix, uy, -(iy * ux));    // |I| sin(theta)
   const R ncs = fma(-ix, ux, -(iy * uy));  // -|I| cos(theta)
   const R theta = angle_abs(k.pc, fabs(sn), ncs, rl, il);  // |(sn,cs)| = |I| since dhat is unit
-  // ln Fs - |diff| / B: the force factor rides in the exponent (Fs exp(x) = exp(x + ln Fs)), clamped so that
-  // exp_fast's integer exponent stays in range for any input (exp(-800) is 0 in double and in float; the clamp
-  // never changes a result)
-  const R a = fmax(fma(dn * rl, k.neg_inv_gamma, k.ln_f_social), R(-800));
+  // log2 Fs - log2(e) |diff| / B: the force factor rides in the exponent (Fs exp(x) = 2^(x log2 e + log2 Fs)), clamped so
+  // that exp2_fast's integer exponent stays in range for any input (2^-1100 is 0 in double and in float; the clamp never
+  // changes a result)
+  const R a = fmax(fma(dn * rl, k.neg_l2e_inv_gamma, k.l2_f_social), R(-1100));
   const R t2 = l2 * (theta * theta);      // (B theta)^2 = gamma^2 |I|^2 theta^2; gamma^2 sits in c_vel / c_ang
   R ev, ea;  // Fs exp(-|diff|/B - (n' B theta)^2), Fs exp(-|diff|/B - (n B theta)^2)
-  exp_fast2(k.pc, fma(k.c_vel, t2, a), fma(k.c_ang, t2, a), ev, ea);
-  if constexpr (NORM_ONLY) {
-#if !SFW_SIGN_OF_ZERO
-    ea = (cw != 0.0) ? ea : R(0);
+#if SFW_SIGN_OF_ZERO
+  exp2_fast2(k.pc, fma(k.c_vel, t2, a), fma(k.c_ang, t2, a), ev, ea);
+#else
+  // sign(theta) = sign(w x diff) is 0 for a pair whose w x diff is exactly 0 (relative rest, motion exactly along the
+  // connecting line — which PERSISTS over the steps for a robot driving straight at a person on its axis): the angular
+  // term is then exactly 0, as lightsfm's is for theta == 0.  The zero enters through the exponent of the term's 2^k
+  // scaling (a compare and ONE select on an integer; as a select on the f64 result it was a compare and two).
+  exp2_fast2_gated(k.pc, fma(k.c_vel, t2, a), fma(k.c_ang, t2, a), __builtin_amdgcn_ballot_w64(cw != 0.0), ev, ea);
 #endif
+  if constexpr (NORM_ONLY) {
     const R q = fma(ev, ev, ea * ea);
     R rq, nq;
     rsqrt_sqrt(fma(R(1), q, tiny), rq, nq);
@@ -564,16 +565,11 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
     fy = R(0);
     return;
   }
-#if SFW_SIGN_OF_ZERO
-  // sign(theta) * exp(...): the sign BIT of cw, one v_bfi_b32.  For w x diff == 0 (relative rest, motion along the
-  // connecting line) that is the sign of a zero — as arbitrary as lightsfm's rounding noise there, but known to the host,
-  // which evaluates the reference's term for exactly these pairs of the handed-over state and takes this one back out
-  // (rest_forces, sfw_capi.hip).  Treating the zero apart cost a compare and two selects in every pair evaluation.
+  // sign(theta) * exp(...): the sign BIT of cw, one v_bfi_b32 (ea is exactly 0 when cw is: its sign is then immaterial).
+  // SFW_SIGN_OF_ZERO=1 (round 3's default, kept for A/B) skips the gate above: the sign of a zero then decides, and the host
+  // takes that term back out for the pairs of the handed-over state (rest_forces, sfw_capi.hip) — but not for an alignment
+  // that persists past it.
   ea = copysign_from(ea, cw);
-#else
-  // sign(theta) * exp(...): sign bit copied from cw, exact zero kept (relative rest)
-  ea = (cw != 0.0) ? copysign_from(ea, cw) : R(0);
-#endif
   const R gx = ix * rl, gy = iy * rl;    // Ihat
   // f = -ev * Ihat - ea * leftNormal(Ihat),  leftNormal(x,y) = (-y, x)
   fx = fma(ea, gy, -(ev * gx));
@@ -613,22 +609,26 @@ __device__ __forceinline__ void desired_force(const agent_consts &k, double px, 
 }
 
 // obstacleForce of one agent: mean over the shared laser points (lightsfm computeObstacleForce; SURVEY.md
-// Appendix A): (1/O) sum_o k exp(-(|p - o| - radius)/sigma) (p - o)/|p - o|.  The factor k rides in the exponent.
+// Appendix A): (1/O) sum_o k exp(-(|p - o| - radius)/sigma) (p - o)/|p - o|.  Evaluated as
+//   [k exp(radius/sigma) / O] * sum_o 2^(-|p - o| log2(e)/sigma) / |p - o| * (p - o):
+// the agent's constant factor multiplies the finished sum (obstacle_scale), so the exponent inside the loop is a plain
+// product with the distance and is formed inside the two fma of the exponential's range reduction (exp2_scaled).
+// 25 VALU instructions per (agent, point), one of them the four-slot v_rsq_f64: 28 issue slots (round 3: 29).
 //
 // Summation order (the same in both kernel organisations, so that they stay bit-identical): the points are cut
-// into OBS_SEG = 8 consecutive segments of L = ceil(O / 8) points; a segment's terms are added in point order
+// into OBS_SEG = 16 consecutive segments of L = ceil(O / 16) points; a segment's terms are added in point order
 // starting from 0, the segment sums are added in segment order.  The register-resident form runs the segments
-// one after the other on the agent's lane; the flat form gives every agent eight lanes, one per segment, and
-// adds the eight partial sums in order (the per-agent pass of a small agent set — a control cycle of the
-// reference's own 5 x 9 grid with a few people and 60..240 laser points — otherwise runs the whole O-point
-// loop on the few lanes that own an agent).
-constexpr int OBS_SEG = 8;
-constexpr int OBS_LANES_MAX_A = 48;  // flat form: up to this many agents the laser-point pass gives every agent eight lanes
+// one after the other on the agent's lane (every lane owns an agent there); the flat form makes every (agent, segment)
+// pair a task and walks the tasks 64 at a time — 4 agents x 16 segments per round — whatever the crowd size: 51 agents
+// are 13 rounds of 45 points of a 720-point scan = 585 evaluations per lane where one lane per agent ran 720 on 51 of
+// the 64 lanes (round 3's form above 48 agents; 8 segments until round 3).
+constexpr int OBS_SEG = 16;
+constexpr int OBS_AGENTS_PER_ROUND = WAVE / OBS_SEG;
 // The points a WAVE-UNIFORM loop reads come straight from global memory through the scalar cache (obs_global: the array
 // as a constant-address-space pointer, so that the loads are s_load and cost neither LDS space nor VALU/VMEM issue);
-// only the flat form's eight-lanes-per-agent pass, whose lanes walk eight different segments, reads them from LDS.
-// Staged in LDS for every form (16 B per point and wave), a 720-point laser scan took the flat form of the target crowd from
-// five waves per SIMD to two and the register form of cfg2 from six to three: 29 % / 27 % more time per point than at 64.
+// the flat form's task loop, whose lanes walk 16 different segments, reads them with per-lane vector loads (the scan is a
+// few KB: L1 hits).  Staged in LDS (16 B per point and wave, round 2), a 720-point laser scan took the flat form of the
+// target crowd from five waves per SIMD to two and the register form of cfg2 from six to three.
 typedef const __attribute__((address_space(4))) double *obs_global_ptr;
 __device__ __forceinline__ obs_global_ptr obs_global(const double *obstacles) {
   return (obs_global_ptr)(const __attribute__((address_space(1))) double *)obstacles;
@@ -637,41 +637,45 @@ __device__ __forceinline__ double2 obs_point(const double2 *obs, int o) { return
 __device__ __forceinline__ double2 obs_point(obs_global_ptr obs, int o) { return double2{obs[2 * o], obs[2 * o + 1]}; }
 template <typename R, typename ObsPtr>
 __device__ __forceinline__ void obstacle_segment(const sfm_consts<R> &k, ObsPtr obs, int o_begin, int o_end,
-                                                 double px, double py, R c0, R neg_inv_sigma, R &ax, R &ay) {
+                                                 double px, double py, R neg_l2e_inv_sigma, R &ax, R &ay) {
   using namespace sfwm;
   ax = R(0);
   ay = R(0);
+  // in a VGPR: the range reduction's first fma also reads the shift constant, and a VOP3 instruction takes one scalar operand
+  const R nis = vgpr_const(neg_l2e_inv_sigma);
 #pragma unroll 4
   for (int o = o_begin; o < o_end; ++o) {
     const double2 q = obs_point(obs, o);
     const R mx = R(px - q.x), my = R(py - q.y);
     R rm, mn;
     rsqrt_sqrt(fma(mx, mx, fma(my, my, tiny_of<R>::v)), rm, mn);
-    const R e = exp_fast(k.pc, fma(mn, neg_inv_sigma, c0)) * rm;  // k exp(-(|md| - radius)/sigma) / |md|
+    const R e = exp2_scaled(k.pc, mn, nis) * rm;  // exp(-|md| / sigma) / |md|
     ax = fma(e, mx, ax);
     ay = fma(e, my, ay);
   }
 }
-// c0 of an agent: radius / sigma + ln k
-template <typename R> __device__ __forceinline__ R obstacle_c0(const agent_consts &c, double radius) {
-  return static_cast<R>(fma(radius, c.inv_sigma, c.ln_f_obstacle));
+// what an agent's sum over the points is multiplied with: k exp(radius / sigma) / O
+template <typename R>
+__device__ __forceinline__ double obstacle_scale(const sfm_consts<R> &k, const agent_consts &c, double radius) {
+  return static_cast<double>(sfwm::exp2_fast(k.pc, static_cast<R>(fma(radius, c.l2e_inv_sigma, c.l2_f_obstacle)))) * c.inv_O;
 }
-// all eight segments on one lane
+// all sixteen segments on one lane
 template <typename R, typename ObsPtr>
 __device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const agent_consts &c, ObsPtr obs,
                                                double px, double py, double radius, double &fx, double &fy) {
   const int O = c.O, L = (O + OBS_SEG - 1) / OBS_SEG;
-  const R c0 = obstacle_c0<R>(c, radius), nis = static_cast<R>(-c.inv_sigma);
+  const R nis = static_cast<R>(-c.l2e_inv_sigma);
   R tx = R(0), ty = R(0);
   for (int seg = 0; seg < OBS_SEG; ++seg) {
-    const int b = seg * L, e = min(b + L, O);
+    const int b = min(seg * L, O), e = min(b + L, O);  // the last segments of a short scan are empty: they add +0
     R ax, ay;
-    obstacle_segment<R, ObsPtr>(k, obs, b, e, px, py, c0, nis, ax, ay);
+    obstacle_segment<R, ObsPtr>(k, obs, b, e, px, py, nis, ax, ay);
     tx = seg == 0 ? ax : tx + ax;
     ty = seg == 0 ? ay : ty + ay;
   }
-  fx = static_cast<double>(tx) * c.inv_O;
-  fy = static_cast<double>(ty) * c.inv_O;
+  const double sc = obstacle_scale<R>(k, c, radius);
+  fx = static_cast<double>(tx) * sc;
+  fy = static_cast<double>(ty) * sc;
 }
 
 // LDS map of one wave.  Agent state lives in PLANES of `cap` doubles each — px, py, vx, vy, the force
@@ -685,14 +689,15 @@ __device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const age
 // the allocation.
 struct lds_layout {
   double *px, *py, *vx, *vy, *fjx, *fjy, *fcx, *fcy;
-  double2 *obs, *gcen;
+  double2 *gcen;
   sfw_robot_step *rsb;  // robot records: one per sample of the wave (register form), two (flat form: this step's
                         // and the prefetched next step's)
   sfw_agent_const *ac;  // the per-agent launch constants as they sit in global memory (48 B records: one address
                         // register per agent reaches every field through the DS offset field)
   double *swp;
-  double2 *opart;       // flat form with laser points: the 64 lanes' partial obstacle sums of one pass
-  double *wr;           // flat form with laser points: the robot's social-work term waiting for its obstacle part
+  double2 *opart;       // flat form with laser points: the 64 lanes' partial obstacle sums of one round of tasks
+  double *wr;           // flat form with laser points: the robot's social-work term waiting for its obstacle part [0] and
+                        // the two components of that part [1], [2]
   int *hasgoal, *dead, *grp, *goff, *gmem;  // hasgoal: register form (one int per 8-byte cell)
   unsigned char *hasgoal8;  // flat form: one byte per agent (crowds of 129..255 agents are LDS-bound in occupancy)
   int hg_stride;        // ints between two slots' hasgoal words (see hg())
@@ -722,11 +727,10 @@ struct lds_layout {
     if (with_frc) {  // flat kernel
       fcx = reinterpret_cast<double *>(take(plane));
       fcy = reinterpret_cast<double *>(take(plane));
-      obs = (O > 0 && A <= OBS_LANES_MAX_A) ? reinterpret_cast<double2 *>(take(sizeof(double2) * O)) : nullptr;  // eight-lanes pass only
       rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * 2));
       swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
       opart = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? 64 : 0)));
-      wr = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? 2 : 0)));
+      wr = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? 4 : 0)));
       hasgoal8 = reinterpret_cast<unsigned char *>(take(static_cast<size_t>(GA)));
       hasgoal = nullptr;
       hg_stride = 1;
@@ -741,7 +745,6 @@ struct lds_layout {
       swp = reinterpret_cast<double *>(take(plane));
       dead = reinterpret_cast<int *>(take(sizeof(int) * REG_DEAD_CAP));
       rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * G));
-      obs = nullptr;  // every loop over the laser points is wave-uniform here: scalar loads from global memory
     }
     ac = reinterpret_cast<sfw_agent_const *>(take(sizeof(sfw_agent_const) * (consts ? A : 0)));
     // group arrays only when an agent carries a group id (the GROUPS kernels): nothing reads them otherwise
@@ -810,7 +813,7 @@ __device__ double2 group_force(const sfm_consts<R> &k, const agent_consts &c, co
     const double rx = cx - px, ry = cy - py;
     const double dist = fast_norm(rx, ry);
     const double x2 = fmin(2.0 * ((n - 1.0) * 0.5 - dist), 700.0);  // -2 (dist - maxd)
-    const double soft = c.f_coherence * sfwm::rcp_nr(1.0 + sfwm::exp_fast(k.pc, x2));
+    const double soft = c.f_coherence * sfwm::rcp_nr(1.0 + sfwm::exp2_fast(k.pc, x2 * 1.4426950408889634074));
     fx = fma(rx, soft, fx);
     fy = fma(ry, soft, fy);
   }
@@ -839,8 +842,8 @@ template <typename R, bool PIN_ALL> __device__ __forceinline__ sfm_consts<R> mak
   // these stay in vector registers (all five in the flat kernel, three in the register-resident one, which has to
   // stay within 80 VGPRs for six waves per SIMD).
   k.lambda = sfwm::vgpr_const(f.lambda);
-  k.neg_inv_gamma = sfwm::vgpr_const(f.neg_inv_gamma);
-  k.ln_f_social = PIN_ALL ? sfwm::vgpr_const(f.ln_f_social) : f.ln_f_social;
+  k.neg_l2e_inv_gamma = sfwm::vgpr_const(f.neg_l2e_inv_gamma);
+  k.l2_f_social = PIN_ALL ? sfwm::vgpr_const(f.l2_f_social) : f.l2_f_social;
   k.c_vel = sfwm::vgpr_const(f.c_vel);
   k.c_ang = PIN_ALL ? sfwm::vgpr_const(f.c_ang) : f.c_ang;
   return k;
@@ -850,12 +853,12 @@ template <typename R, bool PIN_ALL> __device__ __forceinline__ sfm_consts<R> mak
 template <typename R, bool PIN_ALL> __device__ __forceinline__ sfm_consts<R> make_consts(late_launch La) {
   constexpr bool F32 = sizeof(R) == 4;
   sfm_consts<R> k;
-  const R lambda = F32 ? R(La->k.f.lambda) : R(La->k.d.lambda), nig = F32 ? R(La->k.f.neg_inv_gamma) : R(La->k.d.neg_inv_gamma);
-  const R lfs = F32 ? R(La->k.f.ln_f_social) : R(La->k.d.ln_f_social), cv = F32 ? R(La->k.f.c_vel) : R(La->k.d.c_vel);
+  const R lambda = F32 ? R(La->k.f.lambda) : R(La->k.d.lambda), nig = F32 ? R(La->k.f.neg_l2e_inv_gamma) : R(La->k.d.neg_l2e_inv_gamma);
+  const R lfs = F32 ? R(La->k.f.l2_f_social) : R(La->k.d.l2_f_social), cv = F32 ? R(La->k.f.c_vel) : R(La->k.d.c_vel);
   const R ca = F32 ? R(La->k.f.c_ang) : R(La->k.d.c_ang);
   k.lambda = sfwm::vgpr_const(lambda);
-  k.neg_inv_gamma = sfwm::vgpr_const(nig);
-  k.ln_f_social = PIN_ALL ? sfwm::vgpr_const(lfs) : lfs;
+  k.neg_l2e_inv_gamma = sfwm::vgpr_const(nig);
+  k.l2_f_social = PIN_ALL ? sfwm::vgpr_const(lfs) : lfs;
   k.c_vel = sfwm::vgpr_const(cv);
   k.c_ang = PIN_ALL ? sfwm::vgpr_const(ca) : ca;
   return k;
@@ -941,7 +944,7 @@ __device__ __forceinline__ int64_t robot_sample_of_item(const sfw_launch &L, int
 template <bool GROUPS, bool CONSTS>
 __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout &s, int lane, int G, int Gn,
                                            int64_t first_local) {
-  const int A = L.A, O = L.O;
+  const int A = L.A;
   // lds_at() takes offsets into the wave's allocation for LDS addresses: true only while the K2 kernels have no
   // static __shared__ data in front of the dynamic allocation (s.px is the allocation's first byte)
   if (static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char *)(s.px))) != 0u) __builtin_trap();
@@ -950,8 +953,6 @@ __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout
       s.ac[i] = L.agent_c[i];
     }
   }
-  if (s.obs)
-    for (int o = lane; o < O; o += WAVE) s.obs[o] = double2{L.obstacles[2 * o], L.obstacles[2 * o + 1]};
   if constexpr (GROUPS) {
     for (int i = lane; i < A; i += WAVE) s.grp[i] = L.agent_grp[i];
     for (int q = lane; q <= L.NG; q += WAVE) s.goff[q] = L.grp_off[q];
@@ -1677,7 +1678,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       if (contact) s.dead[0] = 2 + step;  // >= 2: rejected by contact at `step`
 #endif
       if (sl == 0 && with_obs) {
-        *s.wr = w;  // Wr = social part + obstacle part: summed below, then added to the robot's social work
+        s.wr[0] = w;  // Wr = social part + obstacle part: summed below, then added to the robot's social work
       } else {
         s.swp[sl] += w;
       }
@@ -1699,51 +1700,36 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       s.fjy[sl] = 0.0;
     }
     if (with_obs) {
-      // Obstacle term: the robot at its pre-step position (Wr's obstacle part), a person at its new position.
-      // Few agents: eight lanes per agent, one per segment of the laser points; many: the agent's lane runs the
-      // eight segments itself (same sums in the same order, see obstacle_force).  8 lanes pay from ~A <= 48 on.
+      // Obstacle term: the robot at its pre-step position (Wr's obstacle part), a person at its new position.  Every
+      // (agent, segment) pair is a task; the wave walks them 64 at a time, 4 agents x 16 segments per round (same sums in
+      // the same order as obstacle_force).  Lane l: segment l / 4 of agent a0 + l % 4 — four neighbouring lanes read the
+      // same point — the points through per-lane loads from global memory (L1).
       __syncthreads();
-      auto apply = [&](int a, double ox, double oy) {
-        if (a == 0) {
-          s.swp[0] += *s.wr + fast_norm(ox, oy);
-        } else {
-          s.fcx[a] += ox;
-          s.fcy[a] += oy;
-        }
-      };
-      if (A <= OBS_LANES_MAX_A) {
-        const int L8 = (c.O + OBS_SEG - 1) / OBS_SEG, seg = lane & (OBS_SEG - 1);
-        const int ob = seg * L8, oe = min(ob + L8, c.O);
-        const R nis = static_cast<R>(-c.inv_sigma);
-        for (int a0 = 0; a0 < A; a0 += WAVE / OBS_SEG) {
-          const int a = a0 + (lane >> 3);
-          R ax = R(0), ay = R(0);
-          if (a < A) {
-            const double rad = GROUPS ? s.ac[a].radius : agent_c[a].radius;
-            obstacle_segment<R, const double2 *>(k, s.obs, ob, oe, s.px[a], s.py[a], obstacle_c0<R>(c, rad), nis, ax, ay);
-          }
-          s.opart[lane] = double2{static_cast<double>(ax), static_cast<double>(ay)};
-          __syncthreads();
-          if (a < A && seg == 0) {
-            R tx = static_cast<R>(s.opart[lane].x), ty = static_cast<R>(s.opart[lane].y);
+      const int Lseg = (c.O + OBS_SEG - 1) / OBS_SEG, seg = lane >> 2, sub = lane & (OBS_AGENTS_PER_ROUND - 1);
+      const int ob = min(seg * Lseg, c.O), oe = min(ob + Lseg, c.O);
+      const R nis = static_cast<R>(-c.l2e_inv_sigma);
+      const double2 *const pts = reinterpret_cast<const double2 *>(La->obstacles);
+      const double *const part = reinterpret_cast<const double *>(s.opart);
+      for (int a0 = 0; a0 < A; a0 += OBS_AGENTS_PER_ROUND) {
+        const int a = a0 + sub;
+        R ax = R(0), ay = R(0);
+        if (a < A) obstacle_segment<R, const double2 *>(k, pts, ob, oe, s.px[a], s.py[a], nis, ax, ay);
+        s.opart[lane] = double2{static_cast<double>(ax), static_cast<double>(ay)};
+        __syncthreads();
+        // the sixteen segment sums in segment order: component x on the agent's first lane, y on its second
+        if (a < A && seg < 2) {
+          R t = static_cast<R>(part[2 * sub + seg]);
 #pragma unroll
-            for (int q = 1; q < OBS_SEG; ++q) {
-              tx += static_cast<R>(s.opart[lane + q].x);
-              ty += static_cast<R>(s.opart[lane + q].y);
-            }
-            apply(a, static_cast<double>(tx) * c.inv_O, static_cast<double>(ty) * c.inv_O);
-          }
-          __syncthreads();
-        }
-      } else {
-        for (int a = lane; a < A; a += WAVE) {
+          for (int q = 1; q < OBS_SEG; ++q) t += static_cast<R>(part[2 * (sub + OBS_AGENTS_PER_ROUND * q) + seg]);
           const double rad = GROUPS ? s.ac[a].radius : agent_c[a].radius;
-          double ox, oy;
-          obstacle_force<R>(k, c, obs_global(La->obstacles), s.px[a], s.py[a], rad, ox, oy);
-          apply(a, ox, oy);
+          const double f = static_cast<double>(t) * obstacle_scale<R>(k, c, rad);
+          if (a == 0) s.wr[1 + seg] = f;
+          else if (seg == 0) s.fcx[a] += f;
+          else s.fcy[a] += f;
         }
         __syncthreads();
       }
+      if (lane == 0) s.swp[0] += s.wr[0] + fast_norm(s.wr[1], s.wr[2]);
       if (lane == 0) {
         s.px[0] = rs.x;
         s.py[0] = rs.y;
@@ -1939,21 +1925,23 @@ void sfw_derive(sfw_launch &L) {
   const sfw_params &p = L.p;
   sfw_force_k<double> &d = L.k.d;
   d.lambda = p.sfm_lambda;
-  d.neg_inv_gamma = -1.0 / p.sfm_gamma;
-  d.ln_f_social = std::log(p.sfm_force_factor_social);  // -inf for Fs = 0: the clamp at -800 makes the force 0
-  d.c_vel = -(p.sfm_n_prime * p.sfm_n_prime) * (p.sfm_gamma * p.sfm_gamma);
-  d.c_ang = -(p.sfm_n * p.sfm_n) * (p.sfm_gamma * p.sfm_gamma);
-  // ln of the obstacle force factor (it rides in the exponent); a factor of 0 becomes exp(-700) = 1e-304
-  d.ln_f_obstacle = p.sfm_force_factor_obstacle > 0 ? std::log(p.sfm_force_factor_obstacle) : -700.0;
-  d.inv_sigma = 1.0 / p.sfm_force_sigma_obstacle;
+  const double l2e = 1.4426950408889634074;  // log2(e): every exponent argument is handed over in log2 units (sfw_math.h)
+  d.neg_l2e_inv_gamma = -l2e / p.sfm_gamma;
+  d.l2_f_social = std::log2(p.sfm_force_factor_social);  // -inf for Fs = 0: the clamp at -1100 makes the force 0
+  d.c_vel = -(p.sfm_n_prime * p.sfm_n_prime) * (p.sfm_gamma * p.sfm_gamma) * l2e;
+  d.c_ang = -(p.sfm_n * p.sfm_n) * (p.sfm_gamma * p.sfm_gamma) * l2e;
+  // log2 of the obstacle force factor (it multiplies the agent's sum as 2^(radius log2(e)/sigma + log2 k)); a factor of 0
+  // becomes 2^-1000 = 1e-301
+  d.l2_f_obstacle = p.sfm_force_factor_obstacle > 0 ? std::log2(p.sfm_force_factor_obstacle) : -1000.0;
+  d.l2e_inv_sigma = l2e / p.sfm_force_sigma_obstacle;
   sfw_force_k<float> &f = L.k.f;
   f.lambda = static_cast<float>(d.lambda);
-  f.neg_inv_gamma = static_cast<float>(d.neg_inv_gamma);
-  f.ln_f_social = static_cast<float>(d.ln_f_social);
+  f.neg_l2e_inv_gamma = static_cast<float>(d.neg_l2e_inv_gamma);
+  f.l2_f_social = static_cast<float>(d.l2_f_social);
   f.c_vel = static_cast<float>(d.c_vel);
   f.c_ang = static_cast<float>(d.c_ang);
-  f.ln_f_obstacle = static_cast<float>(d.ln_f_obstacle);
-  f.inv_sigma = static_cast<float>(d.inv_sigma);
+  f.l2_f_obstacle = static_cast<float>(d.l2_f_obstacle);
+  f.l2e_inv_sigma = static_cast<float>(d.l2e_inv_sigma);
   L.k.f_desired = p.sfm_force_factor_desired;
   L.k.inv_tau = 1.0 / p.sfm_relaxation_time;
   L.k.rr = static_cast<double>(static_cast<float>(p.robot_radius) * static_cast<float>(p.robot_radius));  // ref :617

@@ -36,20 +36,23 @@ __device__ constexpr double kAsinQ[7] = {
 #else
 #error "SFW_ASIN_DEG must be 6, 7 or 8"
 #endif
-// exp(r), |r| <= ln2/2
+// 2^r, |r| <= 1/2.  Every exponential of the path is evaluated in base 2: the arguments arrive in log2 units (the host
+// folds log2(e) into the force constants, sfw_derive), so the range reduction is k = rint(x), r = x - k — an exact
+// subtraction, no product with a rounded ln 2 — and the laser-point term, whose exponent is a plain product, forms it
+// inside the two fma of the reduction (exp2_scaled: one issue slot less per point than exp(fma(d, -1/sigma, c0))).
 #if SFW_EXP_DEG == 9  // max rel err 1.8e-14
-__device__ constexpr double kExpP[10] = {
-    1.00000000000001421e+00, 1.00000000000000777e+00, 4.99999999994189259e-01, 1.66666666665346158e-01,
-    4.16666670498183830e-02, 8.33333339452756693e-03, 1.38888004009164279e-03, 1.98411575417668925e-04,
-    2.48850574964862367e-05, 2.76457905540610794e-06};
+__device__ constexpr double kExp2P[10] = {
+    1.00000000000001399e+00, 6.93147180559949172e-01, 2.40226506956318808e-01, 5.55041086644670403e-02,
+    9.61812919591992048e-03, 1.33335582320688226e-03, 1.54034323372305410e-04, 1.52526540189686452e-05,
+    1.32599492119502467e-06, 1.02095991152988666e-07};
 #elif SFW_EXP_DEG == 8  // max rel err 1.1e-12
-__device__ constexpr double kExpP[9] = {
-    9.99999999999999667e-01, 9.99999999979770404e-01, 4.99999999998101408e-01, 1.66666668911656046e-01, 4.16666668852581981e-02,
-    8.33326607422800632e-03, 1.38888225044999920e-03, 1.99158800697442654e-04, 2.48757945821630479e-05};
+__device__ constexpr double kExp2P[9] = {
+    9.99999999999999556e-01, 6.93147180545924502e-01, 2.40226506958204633e-01, 5.55041094124378298e-02, 9.61812915779665205e-03,
+    1.33334505311817272e-03, 1.54034569411874581e-04, 1.53100893037719350e-05, 1.32549957111681631e-06};
 #elif SFW_EXP_DEG == 7  // max rel err 5.5e-11
-__device__ constexpr double kExpP[8] = {
-    9.99999999959529706e-01, 9.99999999995510036e-01, 5.00000010779330650e-01, 1.66666667863487161e-01,
-    4.16662181408892149e-02, 8.33328352427055441e-03, 1.39485902239979385e-03, 1.99075799133105149e-04};
+__device__ constexpr double kExp2P[8] = {
+    9.99999999959529817e-01, 6.93147180556832998e-01, 2.40226512138058845e-01, 5.55041090633913992e-02,
+    9.61802557216482473e-03, 1.33334784505842571e-03, 1.54697424034518652e-04, 1.53037088618789910e-05};
 #else
 #error "SFW_EXP_DEG must be 7, 8 or 9"
 #endif
@@ -85,8 +88,8 @@ struct poly_consts {
     for (int n = 0; n < SFW_ASIN_DEG; ++n) as[n] = sgpr_const(kAsinQ[n]);
     as[SFW_ASIN_DEG] = vgpr_const(kAsinQ[SFW_ASIN_DEG]);
 #pragma unroll
-    for (int n = 0; n < SFW_EXP_DEG; ++n) ex[n] = sgpr_const(kExpP[n]);
-    ex[SFW_EXP_DEG] = vgpr_const(kExpP[SFW_EXP_DEG]);
+    for (int n = 0; n < SFW_EXP_DEG; ++n) ex[n] = sgpr_const(kExp2P[n]);
+    ex[SFW_EXP_DEG] = vgpr_const(kExp2P[SFW_EXP_DEG]);
   }
 };
 // v_rsq_f64 / v_rcp_f64 deliver ~23 good bits; one Newton step gives ~46.
@@ -103,30 +106,37 @@ __device__ __forceinline__ double rcp_nr(double x) {
   const double e = fma(-x, y, 1.0);
   return fma(e, y, y);                // one Newton step: ~2^-46
 }
-// exp(x) for -1e9 < x < ~700 (the pair term has x <= 0 and is clamped by its caller, the
-// obstacle term x <= radius/sigma): no overflow handling; underflows to 0 through ldexp.
-// Round-to-nearest of x*log2(e) by the 1.5*2^52 shift: the shifted sum holds k in its low
-// mantissa bits (two's complement in the low dword), so no rint and no f64->i32 convert.  One
-// fma reduction step: the error of fl(ln2) reaches r as |k|*2.3e-17 (< 1e-14 relative up to
-// |k| ~ 400, where the result is ~1e-120 and far below anything it is added to).
-__device__ __forceinline__ double exp_fast(const poly_consts &pc, double x) {
-  const double shift = 6755399441055744.0;  // 1.5 * 2^52
-  const double t = fma(x, 1.4426950408889634074, shift);
-  const double k = t - shift;
-  const double r = fma(k, -6.93147180559945286227e-01, x);
+// 2^x for -1e9 < x < ~1000 (the pair term has x <= log2 Fs and is clamped by its caller): no overflow handling;
+// underflows to 0 through ldexp.  Round-to-nearest of x by the 1.5*2^52 shift: the shifted sum holds k in its low
+// mantissa bits (two's complement in the low dword), so no rint and no f64->i32 convert; r = x - k is exact.
+__device__ __forceinline__ double exp2_poly(const poly_consts &pc, double r) {
   double p = pc.ex[SFW_EXP_DEG];
 #pragma unroll
   for (int n = SFW_EXP_DEG - 1; n >= 0; --n) p = fma(p, r, pc.ex[n]);
-  return __builtin_amdgcn_ldexp(p, __double2loint(t));
+  return p;
+}
+__device__ __forceinline__ double exp2_fast(const poly_consts &pc, double x) {
+  const double shift = 6755399441055744.0;  // 1.5 * 2^52
+  const double t = x + shift;
+  const double k = t - shift;
+  return __builtin_amdgcn_ldexp(exp2_poly(pc, x - k), __double2loint(t));
+}
+// 2^(u c): the product is formed inside the two fma of the range reduction (t = u c + shift, r = u c - k, the second one
+// with a single rounding), never on its own.  u c > -1e9.
+__device__ __forceinline__ double exp2_scaled(const poly_consts &pc, double u, double c) {
+  const double shift = 6755399441055744.0;  // 1.5 * 2^52
+  const double t = fma(u, c, shift);
+  const double k = t - shift;
+  return __builtin_amdgcn_ldexp(exp2_poly(pc, fma(u, c, -k)), __double2loint(t));
 }
 // Two exponentials at once, their Horner chains interleaved: a lone wave per SIMD (shared-prefix levels, control-cycle
 // grids) pays the ~8-cycle dependent-issue latency of every link of a chain, two independent chains hide each other's.
-// Same operations on the same values as two exp_fast calls: bit-identical.
-__device__ __forceinline__ void exp_fast2(const poly_consts &pc, double x1, double x2, double &e1, double &e2) {
+// Same operations on the same values as two exp2_fast calls: bit-identical.
+__device__ __forceinline__ void exp2_fast2(const poly_consts &pc, double x1, double x2, double &e1, double &e2) {
   const double shift = 6755399441055744.0;  // 1.5 * 2^52
-  const double t1 = fma(x1, 1.4426950408889634074, shift), t2 = fma(x2, 1.4426950408889634074, shift);
+  const double t1 = x1 + shift, t2 = x2 + shift;
   const double k1 = t1 - shift, k2 = t2 - shift;
-  const double r1 = fma(k1, -6.93147180559945286227e-01, x1), r2 = fma(k2, -6.93147180559945286227e-01, x2);
+  const double r1 = x1 - k1, r2 = x2 - k2;
   double p1 = pc.ex[SFW_EXP_DEG], p2 = pc.ex[SFW_EXP_DEG];
 #pragma unroll
   for (int n = SFW_EXP_DEG - 1; n >= 0; --n) {
@@ -135,6 +145,32 @@ __device__ __forceinline__ void exp_fast2(const poly_consts &pc, double x1, doub
   }
   e1 = __builtin_amdgcn_ldexp(p1, __double2loint(t1));
   e2 = __builtin_amdgcn_ldexp(p2, __double2loint(t2));
+}
+// The same with the second exponential exactly 0 in the lanes whose bit of `on2` (a wave64 lane mask in an SGPR pair:
+// __builtin_amdgcn_ballot_w64) is clear: the integer exponent of its 2^k scaling is replaced by one far below the denormals
+// (v_ldexp_f64 then returns +0) — one v_cndmask_b32 on the integer instead of two on the result.  The replacement is the bit
+// pattern of -4.0f read as an integer (-1 065 353 216): an INLINE constant of the instruction, so it costs neither a VGPR
+// (the register form sits exactly at its 80-VGPR budget) nor the constant bus (a literal next to the vcc mask does not
+// assemble on gfx9); the asm keeps the compiler from materialising it in a register across the rollout all the same.
+__device__ __forceinline__ int gate_exponent(int k, unsigned long long on) {
+  int r;
+  asm("s_mov_b64 vcc, %2\n\tv_cndmask_b32_e32 %0, -4.0, %1, vcc" : "=v"(r) : "v"(k), "s"(on) : "vcc");
+  return r;
+}
+__device__ __forceinline__ void exp2_fast2_gated(const poly_consts &pc, double x1, double x2, unsigned long long on2, double &e1,
+                                                 double &e2) {
+  const double shift = 6755399441055744.0;  // 1.5 * 2^52
+  const double t1 = x1 + shift, t2 = x2 + shift;
+  const double k1 = t1 - shift, k2 = t2 - shift;
+  const double r1 = x1 - k1, r2 = x2 - k2;
+  double p1 = pc.ex[SFW_EXP_DEG], p2 = pc.ex[SFW_EXP_DEG];
+#pragma unroll
+  for (int n = SFW_EXP_DEG - 1; n >= 0; --n) {
+    p1 = fma(p1, r1, pc.ex[n]);
+    p2 = fma(p2, r2, pc.ex[n]);
+  }
+  e1 = __builtin_amdgcn_ldexp(p1, __double2loint(t1));
+  e2 = __builtin_amdgcn_ldexp(p2, gate_exponent(__double2loint(t2), on2));
 }
 // theta = |atan2(y, x)| in [0, pi] for y >= 0, from y, nx = -x and rh = 1 / sqrt(x*x + y*y) (the caller has the
 // reciprocal norm already) — without a division and without a select:
@@ -168,12 +204,18 @@ __device__ __forceinline__ void rsqrt_sqrt(float x, float &rs, float &sq) {
   sq = x * rs;
 }
 __device__ __forceinline__ float rcp_nr(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float exp_fast(const poly_consts &, float x) {
-  return __builtin_amdgcn_exp2f(fmaxf(x * 1.44269504088896340736f, -126.0f));
+// 2^x in float: v_exp_f32; below -150 the result is 0 (clamped so that no denormal-handling mode decides)
+__device__ __forceinline__ float exp2_fast(const poly_consts &, float x) { return __builtin_amdgcn_exp2f(fmaxf(x, -150.0f)); }
+__device__ __forceinline__ float exp2_scaled(const poly_consts &pc, float u, float c) { return exp2_fast(pc, u * c); }
+__device__ __forceinline__ void exp2_fast2(const poly_consts &pc, float x1, float x2, float &e1, float &e2) {
+  e1 = exp2_fast(pc, x1);
+  e2 = exp2_fast(pc, x2);
 }
-__device__ __forceinline__ void exp_fast2(const poly_consts &pc, float x1, float x2, float &e1, float &e2) {
-  e1 = exp_fast(pc, x1);
-  e2 = exp_fast(pc, x2);
+__device__ __forceinline__ void exp2_fast2_gated(const poly_consts &pc, float x1, float x2, unsigned long long on2, float &e1,
+                                                 float &e2) {
+  e1 = exp2_fast(pc, x1);
+  const float e = exp2_fast(pc, x2);
+  asm("s_mov_b64 vcc, %2\n\tv_cndmask_b32_e32 %0, 0, %1, vcc" : "=v"(e2) : "v"(e), "s"(on2) : "vcc");
 }
 __device__ __forceinline__ float angle_abs(const poly_consts &, float y, float nx, float /*rh*/, float hyp) {
   const float x = -nx;

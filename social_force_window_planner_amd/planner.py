@@ -371,6 +371,20 @@ class MultiScorer:
                                                C.byref(best)), "sfw_multi_score_grid")
         return costs, best.as_dict()
 
+    def describe(self):
+        """sfw_multi_describe: devices, exchange and what the RCCL communicators report about themselves."""
+        class Desc(C.Structure):
+            _fields_ = [("ranks", C.c_int32), ("exchange", C.c_int32), ("communicators", C.c_int32), ("comm_size", C.c_int32),
+                        ("rccl_version", C.c_int32), ("devices", C.c_int32 * 64), ("comm_devices", C.c_int32 * 64)]
+
+        d = Desc()
+        lib().sfw_multi_describe.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(lib().sfw_multi_describe(self._m, C.byref(d)), "sfw_multi_describe")
+        n = min(d.ranks, 64)
+        return {"ranks": d.ranks, "exchange": "rccl" if d.exchange == 0 else "host_reduce", "communicators": d.communicators,
+                "comm_size": d.comm_size, "rccl_version": d.rccl_version, "devices": list(d.devices[:n]),
+                "comm_devices": list(d.comm_devices[:n])}
+
     def rank_rows(self, r):
         """(first row, rows) of rank r in the last score_grid."""
         a, b = C.c_int32(), C.c_int32()

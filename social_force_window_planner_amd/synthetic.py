@@ -98,6 +98,10 @@ WORKLOADS = {
     "cfg1": Workload("cfg1", 21, 21, 0, 100, 0.5, seed=1, n_discs=0),
     "cfg2": Workload("cfg2", 128, 128, 20, 200, 1.0, seed=2),
     "cfg2_o64": Workload("cfg2_o64", 128, 128, 20, 200, 1.0, seed=2, n_obstacles=64),  # SURVEY §8d secondary case
+    # what the reference's laserCb really hands over (src/sensor_interface.cpp:117-127: every beam below max_obstacle_dist,
+    # every agent gets the whole scan, :513-524): a 240-point and a 720-point scan
+    "cfg2_o240": Workload("cfg2_o240", 128, 128, 20, 200, 1.0, seed=2, n_obstacles=240),
+    "target_o720": Workload("target_o720", 256, 256, 50, 500, 1.0, seed=6, n_obstacles=720),
     "cfg3": Workload("cfg3", 256, 256, 50, 500, 2.0, seed=3),
     "cfg4": Workload("cfg4", 1024, 1024, 200, 500, 1.0, seed=4),
     "cfg5": Workload("cfg5", 4096, 4096, 100, 500, 1.0, seed=5),

@@ -202,8 +202,8 @@ def test_non_finite_inputs_are_refused(hip_mod):
 
 def test_unsupported_agent_sets(hip_mod):
     """What the device cannot (or, for parity, must not) take is SFW_ERR_UNSUPPORTED, not a failed launch: more agents
-    than one wave's LDS holds (about 2000), more than the 16-bit plane offsets of the pair table reach, and a person that can never
-    move (desired_velocity <= 0: at exact relative rest with its like at every step)."""
+    than one wave's LDS holds (about 2000), more than the 16-bit plane offsets of the pair table reach.  A person that can never
+    move (desired_velocity <= 0, the reference's people_velocity_ = 0) is NOT refused (tests/test_parity_holes_gpu.py scores one)."""
     from social_force_window_planner_amd.planner import SfwError
 
     L = hip_mod.lib()
@@ -213,8 +213,7 @@ def test_unsupported_agent_sets(hip_mod):
     n = len(scene.agents)
     agents = (SfwAgent * n)(*scene.agents)
     agents[3].desired_velocity = 0.0
-    assert L.sfw_set_agents(g._h, C.addressof(agents), n, None, 0) == SFW_ERR_UNSUPPORTED
-    assert b"desired_velocity" in L.sfw_last_error(g._h)
+    assert L.sfw_set_agents(g._h, C.addressof(agents), n, None, 0) == SFW_OK
     agents[3].desired_velocity = 1.0
     agents[0].desired_velocity = 0.0  # the robot is not integrated by the social-force model: anything goes
     assert L.sfw_set_agents(g._h, C.addressof(agents), n, None, 0) == SFW_OK

@@ -28,8 +28,8 @@ def _port():
 
 
 def test_single_gpu_line():
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--verify", "--extras",
-                        "upload,resident,cfg2,cfg2_o64,inproc_multi", "--extra-steps", "3"], cwd=ROOT,
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--extras",
+                        "upload,resident,cfg2,cfg2_o64,cfg2_o240,inproc_multi", "--extra-steps", "3"], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -58,14 +58,25 @@ def test_single_gpu_line():
     assert rf["hbm"]["unit"] == "GB/s" and rf["hbm"]["frac"] < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["all_cores"]["cores"] >= 1
-    assert d["verify"]["same_invalid_set"] and d["verify"]["max_rel_err"] <= 1e-9
+    # the oracle on the headline grid itself, by default, outside the timed region
+    vf = d["verify"]
+    assert vf["samples"] == 65536 and vf["coverage"].startswith("the whole grid")
+    assert vf["invalid_set_equal"] is True and vf["cmd_vel_match"] is True and vf["max_rel_err"] <= 1e-9
+    assert vf["oracle_cmd_vel"]["index"] == d["cmd_vel"]["index"] and vf["same_cmd_vel_as_timed_steps"] is True
+    # the per-cycle world upload is outside the timed step; the line says so and prices it
+    assert "world_state" in d["config"] and 0 < d["value_incl_world_upload"] < d["value"]
+    assert "240 laser points" in ex["cfg2_o240"]["workload"] and ex["cfg2_o240"]["value"] < ex["cfg2_o64"]["value"]
+    assert 0 < ex["cfg2_o240"]["roofline_frac"] < 1
+    assert im["R8"]["collective"]["exchange"] == "host_reduce" and im["R8"]["collective"]["devices"] == [0] * 8
+    assert len(im["R8"]["levels"]) == 8 and sum(im["R8"]["rows"]) == 256
     assert d["value"] / cb["value"] > 100  # sanity: the GPU path is not the CPU path
 
 
 def test_two_ranks_on_one_gpu_over_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--no-cpu-baseline", "--extras", "inproc_multi", "--inproc-workload", "cfg2"]
+           "--backend", "gloo", "--no-cpu-baseline", "--extras", "inproc_multi,target_strong", "--inproc-workload", "cfg2",
+           "--extra-steps", "3"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d2 = _last_json(r.stdout)
@@ -73,13 +84,24 @@ def test_two_ranks_on_one_gpu_over_gloo():
     assert abs(d2["config"]["samples_per_gpu"] - 65536) < 0.15 * 65536  # blocks of equal planned work, not of equal row counts
     assert len(d2["per_rank"]["social_kernel_ms"]) == 2 and min(d2["per_rank"]["exchange_us"]) > 0
     assert len(d2["per_rank"]["executed_share"]) == 2 and all(0 < v <= 1 for v in d2["per_rank"]["executed_share"])
+    assert len(d2["per_rank"]["levels"]) == 2
+    # the record says what the collective was: backend, group size, every rank's device
+    co = d2["collective"]
+    assert co["backend"] == "gloo" and co["world_size"] == 2 and len(co["rank_devices"]) == 2 and co["rccl_version"]
+    # rank 0's row block against the oracle (budgeted sub-grid or the whole block) + the globally selected sample
+    vf = d2["verify"]
+    assert vf["invalid_set_equal"] is True and vf["max_rel_err"] <= 1e-9 and vf["selected_sample"]["rel_err"] <= 1e-9
+    assert vf["selected_sample"]["index"] == d2["global_cmd_vel"]["index"]
+    # strong scaling of the target grid itself next to the weak-scaling headline
+    ts = d2["extra"]["target_strong"]
+    assert ts["scaling"] == "strong" and sum(ts["per_rank"]["rows"]) == 256 and len(ts["per_rank"]["levels"]) == 2
     # rank 0 alone through sfw_multi_score_grid (one process, two ranks): printed next to the torchrun numbers
     im = d2["extra"]["inproc_multi_cfg2"]
     assert im["ranks"] == 2 and im["value"] > 1e6 and im["enqueue_us"] > 0, im
     assert d2["extra"]["inproc_multi_target"]["ranks"] == 2
     # the same 512x256 grid scored by one process selects the same command
     r1 = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--grid", "512x256",
-                         "--no-cpu-baseline", "--no-extra"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+                         "--no-cpu-baseline", "--no-extra", "--no-verify"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r1.returncode == 0, r1.stderr[-2000:]
     d1 = _last_json(r1.stdout)
     assert d2["global_cmd_vel"]["index"] == d1["cmd_vel"]["index"]
@@ -93,7 +115,7 @@ def test_a_stuck_one_process_leg_costs_its_entry_not_the_line():
     a limit no child can meet, the entries carry an error and the headline line is still printed."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo",
-           "--no-cpu-baseline", "--extras", "inproc_multi", "--inproc-workload", "cfg2", "--inproc-timeout", "0.01"]
+           "--no-cpu-baseline", "--no-verify", "--extras", "inproc_multi", "--inproc-workload", "cfg2", "--inproc-timeout", "0.01"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)

@@ -7,6 +7,7 @@ and identical-argmin checks are exact.
 """
 import dataclasses
 import math
+import os
 
 import numpy as np
 import pytest
@@ -229,6 +230,42 @@ def test_cfg2_full_grid(oracle_mod, hip_mod):
     _assert_parity(oc, ob, gc, gb, RTOL_F64)
 
 
+def _strided(n, k):
+    """k indices spread evenly over range(n), both ends included"""
+    return np.unique(np.linspace(0, n - 1, k).round().astype(int))
+
+
+def _assert_subgrid_parity(oracle_mod, scene, costs, rows, cols, rtol=RTOL_F64):
+    """A strided sub-grid of a FULL-SIZE launch's cost vector against the oracle, sample by sample."""
+    w = scene.workload
+    o = oracle_mod.OracleScorer(_params_for(w))
+    o.load_scene(scene)
+    oc, _ = o.score_grid(scene.robot_state, scene.linvels[rows], scene.angvels[cols], scene.goal_args,
+                         n_threads=os.cpu_count())
+    gc = costs.reshape(len(scene.linvels), len(scene.angvels))[np.ix_(rows, cols)].ravel()
+    assert np.array_equal(oc < 0, gc < 0) and np.array_equal(oc[oc < 0], gc[gc < 0])
+    v = oc >= 0
+    worst = float(np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v]))) if v.any() else 0.0
+    assert worst <= rtol, f"max rel err {worst:.3e}"
+    return int(v.sum()), worst
+
+
+def test_target_full_grid(oracle_mod, hip_mod):
+    """The headline grid ITSELF (north star: 256 x 256 samples, 50 pedestrians, 40 steps; the launch with the 10-level
+    shared-prefix tree that bench.py times) against the oracle on every host thread: identical sentinel set, every cost
+    within 1e-9, identical index / vx / vtheta / n_valid (selection rule: ref :394-414, costs: ref :475-676)."""
+    scene, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, syn.WORKLOADS["target"], n_threads=os.cpu_count())
+    assert len(oc) == 65536 and (oc >= 0).sum() > 30000
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+def test_cfg3_full_grid(oracle_mod, hip_mod):
+    """BASELINE.json configs[2] at full size (256 x 256, 50 pedestrians, 500 x 500 map, 80 steps) against the oracle."""
+    scene, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, syn.WORKLOADS["cfg3"], n_threads=os.cpu_count())
+    assert len(oc) == 65536 and (oc >= 0).sum() > 30000
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
 def test_target_subgrid(oracle_mod, hip_mod):
     """North-star target shape (50 pedestrians, 40 steps), 32x32 samples."""
     w = dataclasses.replace(syn.WORKLOADS["target"], nv=32, nw=32)
@@ -318,9 +355,13 @@ def test_cfg3_full_size_properties(oracle_mod, hip_mod):
     assert np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64
 
 
-def test_cfg4_full_size_properties(hip_mod):
-    """1024x1024 grid, 200 pedestrians (dense crowd): the LDS people-tiling stress config."""
-    _full_size_properties(hip_mod, syn.WORKLOADS["cfg4"], [0, 511, 1023])
+def test_cfg4_full_size_properties(oracle_mod, hip_mod):
+    """1024x1024 grid, 200 pedestrians (dense crowd): the LDS people-tiling stress config.  The size-independent
+    properties, then a 45 x 45 sub-grid spread over the WHOLE grid (not a corner) of the full-size launch's own cost
+    vector against the oracle."""
+    scene, costs, best = _full_size_properties(hip_mod, syn.WORKLOADS["cfg4"], [0, 511, 1023])
+    n_valid, _ = _assert_subgrid_parity(oracle_mod, scene, costs, _strided(1024, 45), _strided(1024, 45))
+    assert n_valid > 1000
 
 
 def test_cfg4_spec_crowd_full_size(oracle_mod, hip_mod):
@@ -330,10 +371,11 @@ def test_cfg4_spec_crowd_full_size(oracle_mod, hip_mod):
     w = dataclasses.replace(syn.WORKLOADS["cfg4"], people_r_in=0.8)
     scene, costs, best = _full_size_properties(hip_mod, w, [0, 511, 1023])
     assert best["index"] == -1 and best["n_valid"] == 0 and set(np.unique(costs).tolist()) <= {-1.0, -2.0}
-    rows, cols = np.arange(0, 1024, 128), np.arange(0, 1024, 128)
+    rows, cols = _strided(1024, 45), _strided(1024, 45)
     o = oracle_mod.OracleScorer(_params_for(w))
     o.load_scene(scene)
-    oc, _ = o.score_grid(scene.robot_state, scene.linvels[rows], scene.angvels[cols], scene.goal_args, n_threads=64)
+    oc, _ = o.score_grid(scene.robot_state, scene.linvels[rows], scene.angvels[cols], scene.goal_args,
+                         n_threads=os.cpu_count())
     assert np.array_equal(oc, costs.reshape(1024, 1024)[np.ix_(rows, cols)].ravel())
 
 

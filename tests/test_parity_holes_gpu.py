@@ -11,6 +11,7 @@ All through the C ABI (ctypes), all against oracle/ on the same inputs.
 """
 import dataclasses
 import math
+import os
 
 import numpy as np
 import pytest
@@ -266,15 +267,30 @@ def test_cfg5_one_rank_shard_full_size(oracle_mod, hip_mod):
     assert best["index"] == sel and best["n_valid"] == int((costs >= 0).sum())
     assert key[3] == -float(lo * full.nw + sel)
     assert np.all(np.isfinite(costs)) and np.all((costs >= 0) | (costs == -1.0) | (costs == -2.0))
+    # a 24 x 64 sub-grid spread over the whole shard, out of the full-size launch's own cost vector, against the oracle
     o = oracle_mod.OracleScorer(p)
     o.load_scene(scene)
-    cols = np.arange(0, full.nw, 64)  # 64 samples of each of two rows
-    for r in (0, 511):
-        oc, _ = o.score_grid(scene.robot_state, lin[r:r + 1], ang[cols], scene.goal_args, n_threads=64)
-        gsub = grid[r, cols]
-        assert np.array_equal(oc < 0, gsub < 0)
-        v = oc >= 0
-        assert np.max(np.abs(gsub[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64
+    rows = np.unique(np.linspace(0, len(lin) - 1, 24).round().astype(int))
+    cols = np.unique(np.linspace(0, full.nw - 1, 64).round().astype(int))
+    oc, _ = o.score_grid(scene.robot_state, lin[rows], ang[cols], scene.goal_args, n_threads=os.cpu_count())
+    gsub = grid[np.ix_(rows, cols)].ravel()
+    assert np.array_equal(oc < 0, gsub < 0) and np.array_equal(oc[oc < 0], gsub[gsub < 0])
+    v = oc >= 0
+    assert v.sum() > 500 and np.max(np.abs(gsub[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64
+
+
+def test_cfg5_strided_subgrid_f64(oracle_mod, hip_mod):
+    """64 x 64 samples spread over the WHOLE 4096 x 4096 cfg5 grid (every 65th row and column, both ends included)
+    against the oracle, selection included."""
+    full = syn.WORKLOADS["cfg5"]
+    lin_all, ang_all = syn.generalised_sampler(full.nv, full.nw)
+    rows = np.unique(np.linspace(0, full.nv - 1, 64).round().astype(int))
+    cols = np.unique(np.linspace(0, full.nw - 1, 64).round().astype(int))
+    scene = syn.make_scene(dataclasses.replace(full, nv=8, nw=8))
+    scene.linvels, scene.angvels = lin_all[rows], ang_all[cols]
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, _params_for(full), n_threads=os.cpu_count())
+    assert len(oc) == 4096 and (oc >= 0).sum() > 1000
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
 
 
 # ---------------------------------------------------------------------------
@@ -476,3 +492,90 @@ def test_pairs_moving_exactly_along_their_connecting_line(oracle_mod, hip_mod, r
     assert np.array_equal(oc < 0, gc < 0)
     v = oc >= 0
     assert np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= RTOL_NORTH_STAR
+
+
+# ---------------------------------------------------------------------------
+# an alignment that PERSISTS past the handed-over state
+# ---------------------------------------------------------------------------
+def _on_axis_scene(n_on_axis, nv=5, nw=9, sampler="reference"):
+    """Robot at the origin heading along +x, the people EXACTLY on that axis ahead of it, walking at it along the axis, no
+    other agent, no laser point: for the samples with angvel == 0 every pair keeps w x diff == 0 at every step and
+    lightsfm's theta is exactly 0 (I points along dhat for all these pairs) — sign(theta) = 0, no lateral force, ever."""
+    w = dataclasses.replace(syn.WORKLOADS["ref5x9"], nv=nv, nw=nw, n_people=n_on_axis, sampler=sampler, seed=901)
+    scene = syn.make_scene(w)
+    ag = scene.agents
+    # speeds such that I = lambda w + dhat points along dhat for every pair (v_near - v_far > -1/lambda = -0.5): theta is 0, not
+    # +-pi (a pair separating faster than that gets lightsfm's exp(-(n B pi)^2) lateral kick with the sign of a zero at step 0 —
+    # the host-evaluated term — and from there on decides signs by 1e-24 m offsets: _collinear_scene covers that case)
+    spots = [(3.0, -0.9), (5.0, -0.5), (7.5, -0.45)]
+    for i in range(1, n_on_axis + 1):
+        x, vx = spots[i - 1]
+        a = ag[i]
+        a.x, a.y, a.vx, a.vy = x, 0.0, vx, 0.0
+        a.goal_x, a.goal_y = x + 2.0 * vx, 0.0
+    return scene
+
+
+@pytest.mark.parametrize("n_on_axis", [1, 2, 3])
+def test_alignment_that_persists_past_the_handed_over_state(oracle_mod, hip_mod, n_on_axis):
+    """with the sign BIT of w x diff deciding also for a zero, the straight-ahead samples of such a scene
+    got a full-magnitude lateral force from step 1 on and Wp = sqrt(2) ev.  The kernels keep an exact zero there
+    (exp_fast2_gated): identical sentinel sets and selection, costs within 1e-9 in both organisations and with f32 forces;
+    and the scene exercises it — the oracle's own straight-ahead costs move by > 1e-4 once a person is 1e-9 m off the axis."""
+    from social_force_window_planner_amd._abi import SFW_K2_FLAT, SFW_K2_REGISTER
+
+    scene = _on_axis_scene(n_on_axis)
+    p = default_params()
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, p)
+    straight = np.flatnonzero((np.tile(scene.angvels, len(scene.linvels)) == 0.0) & (oc >= 0))
+    assert len(straight) >= 3
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+    for form in (SFW_K2_REGISTER, SFW_K2_FLAT):
+        g = hip_mod.HipScorer(p)
+        g.set_k2_form(form)
+        g.load_scene(scene)
+        c2, b2 = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+        assert np.array_equal(c2, gc) and b2 == gb
+    # a larger grid with the same property (an odd column count has the angvel == 0 column): register form, shared prefix
+    big = _on_axis_scene(n_on_axis, nv=96, nw=97, sampler="generalised")
+    oc3, ob3, gc3, gb3 = _both(oracle_mod, hip_mod, big, p, n_threads=os.cpu_count())
+    _assert_parity(oc3, ob3, gc3, gb3, RTOL_F64)
+    # the discontinuity is there: 1e-9 m off the axis and the oracle's straight-ahead samples cost something else
+    pert = _on_axis_scene(n_on_axis)
+    pert.agents[1].y = 1e-9
+    o = oracle_mod.OracleScorer(p)
+    o.load_scene(pert)
+    oc2, _ = o.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args, n_threads=8)
+    moved = np.max(np.abs(oc2[straight] - oc[straight]) / np.abs(oc[straight]))
+    assert moved > 1e-4, f"scene does not exercise the discontinuity (oracle moved by {moved:.1e})"
+    pf = default_params(precision=SFW_PRECISION_F32)
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, pf, oracle_params=p)
+    assert np.array_equal(oc < 0, gc < 0)
+    v = oc >= 0
+    assert np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= RTOL_NORTH_STAR and gb["index"] == ob["index"]
+
+
+def test_people_that_can_never_move(oracle_mod, hip_mod):
+    """desired_velocity = 0 (the reference's people_velocity_ = 0, sensor_interface.cpp:503): accepted, and such people stay
+    where they stand (the speed clamp of updatePosition).  Rows with linvel > 0 — the robot keeps a non-zero twist, so no
+    pair that enters the social work is ever at exact relative rest — match the oracle like any other scene.  (A STOPPED
+    robot next to such a person is at relative rest with it at every step: there lightsfm's sign(theta) is the rounding
+    noise of two atan2 — 0 for 96 % of the geometries, else +-1 — and the kernels' is 0: DESIGN.md §5.)"""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=9, nw=9, n_people=14, seed=733)
+    scene = syn.make_scene(w)
+    ag = scene.agents
+    for i in (2, 5, 6, 11):
+        _stand(ag[i])
+        ag[i].desired_velocity = 0.0
+    ag[8].desired_velocity = 0.0   # walking when handed over, pinned by the clamp from the first step on
+    lin = scene.linvels[1:]        # linvel > 0
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, default_params(), lin=lin)
+    assert (oc >= 0).sum() > 20
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+    # and they matter: the same people free to move score differently
+    for i in (2, 5, 6, 8, 11):
+        ag[i].desired_velocity = 1.0
+    o = oracle_mod.OracleScorer(default_params())
+    o.load_scene(scene)
+    oc2, _ = o.score_grid(scene.robot_state, lin, scene.angvels, scene.goal_args, n_threads=8)
+    assert not np.allclose(oc, oc2, rtol=1e-6)

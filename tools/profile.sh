@@ -9,7 +9,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --workload $WL --no-cpu-baseline --no-extra"
+BENCH="python $REPO/bench.py --workload $WL --no-cpu-baseline --no-extra --no-verify"
 D=/tmp/prof_$TAG
 rm -rf $D
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- $BENCH > $OUT/${TAG}_bench.json 2> $D.err

@@ -5,7 +5,7 @@ REPO=$(pwd); cd /tmp && export TMPDIR=/tmp
 for lib in "$@"; do
   if [ "$lib" = "-" ]; then unset SFW_HIP_LIB; else export SFW_HIP_LIB=$REPO/$lib; fi
   D=/tmp/st_$$_$(basename $lib .so); rm -rf $D
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python $REPO/bench.py --workload $WL --no-cpu-baseline --no-extra --steps 10 --warmup 2 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python $REPO/bench.py --workload $WL --no-cpu-baseline --no-extra --no-verify --steps 10 --warmup 2 > /dev/null 2>&1
   echo "== $lib"
   python - $D <<'P'
 import csv,glob,sys,collections
