@@ -139,11 +139,16 @@ struct sfw_planner_s {
   bool staged = false, launched = false, launched_timed = false;
   bool timing = false;  // sfw_set_timing: record the per-kernel events sfw_last_launch_ms reads
   int k2_form = SFW_K2_AUTO;     // sfw_set_k2_form / SFW_FORCE_FLAT
+  // shape of the device the launch heuristics are scaled to: compute units (hipDeviceProp_t.multiProcessorCount: 256 on a
+  // whole MI355X, 32 on a CPX partition) and XCDs (32 CUs each); SFW_DEVICE_CUS / SFW_DEVICE_XCDS in the environment of
+  // sfw_create override them (a test pretends 32 CUs: the plan changes, the results may not)
+  int n_cu = SFW_DEFAULT_CUS, n_xcd = SFW_DEFAULT_CUS / SFW_CUS_PER_XCD;
   // sfw_set_points_capture: a grid small enough for the fused K1 (a control cycle's samples) leaves its Trajectory points,
   // point counts and contact steps during the scoring launch itself, in one buffer -> the dump is one D2H copy
   // K1a of a single-chunk grid is enqueued by the STAGE, before the shared-prefix planning (25..45 us of host work that
   // the pose rollout does not depend on): early_poses says the staged grid's robot-step table is already in the stream
   bool early_poses = false;
+  bool early_poses_timed = false;  // ... and the stage recorded ev[0] in front of it (timing was on at stage time)
   bool capture_points = false, captured = false;
   int cap_S = 0;                 // step count the capturing launch ran with (the dump's layout)
   dev_buf<char> cap;             // points (24 S T bytes) | n_points (4 T) | contact steps (4 T)
@@ -210,6 +215,15 @@ int hip_fail(sfw_handle h, hipError_t e, const char *what) {
     if (e_ != hipSuccess) return hip_fail((h), e_, #call); \
   } while (0)
 
+// SFW_DEVICE_CUS in the environment: pretend a device of that many compute units (planning heuristics only)
+int env_device_cus(int fallback) {
+  if (const char *b = std::getenv("SFW_DEVICE_CUS")) {
+    const long v = std::atol(b);
+    if (v >= 1 && v <= 4096) return static_cast<int>(v);
+  }
+  return fallback;
+}
+
 bool all_finite(const double *v, size_t n) {
   for (size_t i = 0; i < n; ++i)
     if (!std::isfinite(v[i])) return false;
@@ -273,6 +287,8 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.grp_mem = h->d_grp_mem;
   L.NG = h->st_NG;
   L.n_grp_mem = h->st_n_grp_mem;
+  L.n_cu = h->n_cu;
+  L.n_xcd = h->n_xcd;
   sfw_derive(L);
   L.pair_tab = h->pair_tab.p;
   L.status = h->status.p;
@@ -345,8 +361,8 @@ void velocity_classes(const std::vector<double> &targets, double v0, double a_ma
 // round: below one wave per issue slot of the GPU the FP64 dependency chains are exposed and a step takes
 // about 0.45 of a full round whatever the item count (cfg2: 10 us against 22 us), above it time is
 // proportional to the waves.
-double step_cost(double items, double items_per_wave) {
-  const double capacity = 1024.0 * 5.5;  // waves resident at once: 1024 SIMDs x 5-6 waves
+double step_cost(double items, double items_per_wave, int cus) {
+  const double capacity = 4.0 * cus * 5.5;  // waves resident at once: 4 SIMDs per CU x 5-6 waves (1024 SIMDs on a whole MI355X)
   const double x = items / items_per_wave / capacity;
   return x <= 1.0 ? 0.45 + 0.55 * x : x;
 }
@@ -403,16 +419,16 @@ void classes_of_grid(prefix_classes &pc, const std::vector<double> &lin, const s
 // The levels' end steps.  A level ending at step p costs (p - q) steps over classes(p) items plus a
 // launch and the class records (0.4 to 1.0 of a round); the suffix costs (S - p) steps over all
 // samples.  Dynamic programme over the end step of the last level; empty when sharing does not pay.
-std::vector<int> choose_levels(const prefix_classes &pc, int64_t T, int S, double samples_per_wave) {
+std::vector<int> choose_levels(const prefix_classes &pc, int64_t T, int S, double samples_per_wave, int cus) {
   std::vector<int> steps;
-  const double full = step_cost(static_cast<double>(T), samples_per_wave);
+  const double full = step_cost(static_cast<double>(T), samples_per_wave, cus);
   const int last_p = std::min<int>(pc.max_p, static_cast<int>(std::max(pc.rows.n.size(), pc.cols->n.size())));
   std::vector<double> best(static_cast<size_t>(last_p) + 1, 0.0);
   std::vector<int> from(static_cast<size_t>(last_p) + 1, 0);
   double best_total = S * full;
   int best_end = 0;
   for (int p = 1; p <= last_p; ++p) {
-    const double c = step_cost(static_cast<double>(pc.n_rows_at(p)) * pc.n_cols_at(p), samples_per_wave);
+    const double c = step_cost(static_cast<double>(pc.n_rows_at(p)) * pc.n_cols_at(p), samples_per_wave, cus);
     // per extra launch: dispatch + class records for an under-filled level; a level that fills the GPU
     // also pays its ramp-up and tail (measured: 0.4 / 1.0 pick the fastest plans at cfg2 / target)
     const double launch_cost = c < 1.0 ? 0.4 : 1.0;
@@ -438,7 +454,7 @@ std::vector<int> choose_levels(const prefix_classes &pc, int64_t T, int S, doubl
 // the running sum passes r/R of the total.  Equal row counts when nothing is shared.  Each rank still makes its own plan
 // for its block; costs do not depend on the cut.
 void plan_row_blocks(const std::vector<double> &lin, const std::vector<double> &ang, double vx0, double vth0, double acc_x,
-                     double acc_theta, double dt, int S, int A, int R, int form, std::vector<int32_t> &row0) {
+                     double acc_theta, double dt, int S, int A, int R, int form, int cus, std::vector<int32_t> &row0) {
   const int64_t nv = static_cast<int64_t>(lin.size()), nw = static_cast<int64_t>(ang.size());
   row0.assign(static_cast<size_t>(R) + 1, 0);
   for (int r = 0; r <= R; ++r) row0[static_cast<size_t>(r)] = static_cast<int32_t>((static_cast<int64_t>(r) * nv) / R);
@@ -447,7 +463,7 @@ void plan_row_blocks(const std::vector<double> &lin, const std::vector<double> &
   classes_of_grid(pc, lin, ang, vx0, vth0, acc_x, acc_theta, dt, S);
   // the levels of the WHOLE grid's plan (its class counts are the whole grid's): the blocks' own plans differ in detail,
   // the relative weights along the row axis do not
-  const std::vector<int> steps = choose_levels(pc, nv * nw, S, static_cast<double>(sfw_samples_per_wave(A, (nv / R) * nw, form)));
+  const std::vector<int> steps = choose_levels(pc, nv * nw, S, static_cast<double>(sfw_samples_per_wave(A, (nv / R) * nw, form, cus)), cus);
   if (steps.empty()) return;
   std::vector<double> w(static_cast<size_t>(nv), static_cast<double>(nw) * (S - steps.back()));
   int prev = 0;
@@ -495,7 +511,7 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
     for (int p : h->prefix_env)
       if (p >= 1 && p <= pc.max_p) steps.push_back(p);
   } else {
-    steps = choose_levels(pc, T, S, static_cast<double>(sfw_samples_per_wave(h->st_A, std::min<int64_t>(T, rows_per_chunk * h->nw), h->k2_form)));
+    steps = choose_levels(pc, T, S, static_cast<double>(sfw_samples_per_wave(h->st_A, std::min<int64_t>(T, rows_per_chunk * h->nw), h->k2_form, h->n_cu)), h->n_cu);
   }
   if (steps.empty()) return SFW_OK;
   const size_t n_lv = steps.size();
@@ -664,6 +680,7 @@ int plan_tables(sfw_handle h, bool may_start_poses = false) {
     fill_launch(h, L, 0, T, T);
     if (!sfw_rollout_is_fused(L)) {  // (the fused small-grid K1 is one launch with the costmap part, and may capture points)
       if (h->timing) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
+      h->early_poses_timed = h->timing;
       SFW_HIP(h, sfw_launch_rollout_poses(L, h->stream));
       h->early_poses = true;
     }
@@ -675,7 +692,7 @@ int plan_tables(sfw_handle h, bool may_start_poses = false) {
 
 // The agent / laser-point set must fit one wave's LDS allocation (160 KiB per CU).
 int check_lds(sfw_handle h, int64_t items) {
-  const size_t lds = sfw_social_lds_bytes(h->st_A, h->st_O, h->st_NG, h->st_n_grp_mem, items, h->k2_form);
+  const size_t lds = sfw_social_lds_bytes(h->st_A, h->st_O, h->st_NG, h->st_n_grp_mem, items, h->k2_form, h->n_cu);
   if (h->st_A > 0 && lds > 160 * 1024)
     return fail(h, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
   return SFW_OK;
@@ -793,7 +810,9 @@ int launch_common(sfw_handle h) {
   const bool prefix = !h->prefix_steps.empty() && h->prefix_S == S && h->prefix_chunk <= chunk;
   if (prefix) chunk = h->prefix_chunk;
   const bool timing = h->timing;
-  const bool poses_done = h->early_poses && chunk >= T;  // the stage enqueued K1a of this (single-chunk) grid already
+  // the stage enqueued K1a of this (single-chunk) grid already — unless sfw_set_timing(1) arrived since: the events of a
+  // timed launch bracket its own kernels, so the pose rollout runs again behind a freshly recorded ev[0]
+  const bool poses_done = h->early_poses && chunk >= T && (!h->timing || h->early_poses_timed);
   h->early_poses = false;                                 // ... once: a second launch of the same stage rolls out again
   if (timing) {
     SFW_HIP(h, h->clock.reserve(4));
@@ -990,6 +1009,18 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
     if (mb > 0) h->table_budget_bytes = static_cast<size_t>(mb) << 20;
   }
   hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) {
+    // the launch heuristics (shared-prefix cost model, organisation thresholds, XCD-contiguous block order) scale with the
+    // device: a CPX partition of an MI355X shows 32 compute units on one XCD where the whole chip shows 256 on eight
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+    h->n_cu = env_device_cus(h->n_cu);
+    h->n_xcd = std::max(1, h->n_cu / SFW_CUS_PER_XCD);
+    if (const char *b = std::getenv("SFW_DEVICE_XCDS")) {
+      const long v = std::atol(b);
+      if (v >= 1 && v <= 64) h->n_xcd = static_cast<int>(v);
+    }
+  }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_poses, hipEventDisableTiming);
@@ -1126,13 +1157,14 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   const int n_mem = off.back();
   // the set has to fit one wave's LDS allocation whatever the grid (the flat form of one sample is the smallest): refused
   // here, before the all-pairs scan below and long before a launch
-  if (A > 0 && sfw_social_lds_bytes(A, O, static_cast<int>(ids.size()), n_mem, 1, SFW_K2_FLAT) > 160 * 1024)
+  if (A > 0 && sfw_social_lds_bytes(A, O, static_cast<int>(ids.size()), n_mem, 1, SFW_K2_FLAT, h->n_cu) > 160 * 1024)
     return fail(h, SFW_ERR_UNSUPPORTED, "set_agents: agent/obstacle set does not fit the 160 KiB LDS of one CU");
   if (mem.empty()) mem.push_back(0);
   // host blob (uploaded with the next stage): pos | vel | const | obstacles | grp | off | mem
   auto up16 = [](size_t b) { return (b + 15) & ~size_t(15); };
   const size_t o_pos = 0, o_vel = o_pos + up16(16 * An), o_cst = o_vel + up16(16 * An),
-               o_obs = o_cst + up16(sizeof(sfw_agent_const) * An), o_grp = o_obs + up16(16 * On),
+               o_obs = o_cst + up16(sizeof(sfw_agent_const) * An), o_grp = o_obs + up16(16 * On) + 64,  // + 64: the kernels read the points in groups of four (s_load_dwordx16)
+
                o_off = o_grp + up16(4 * An), o_mem = o_off + up16(4 * off.size()),
                total = o_mem + up16(4 * mem.size());
   h->h_agents.assign(total, 0);
@@ -1280,7 +1312,8 @@ int sfw_plan_shared_prefix(const double *linvels, int32_t nv, const double *angv
   const std::vector<double> lin(linvels, linvels + nv), ang(angvels, angvels + nw);
   prefix_classes pc;
   classes_of_grid(pc, lin, ang, vx0, vtheta0, acc_x, acc_theta, sim_time / num_steps, num_steps);
-  const std::vector<int> steps = choose_levels(pc, T, num_steps, static_cast<double>(sfw_samples_per_wave(n_agents, T, SFW_K2_AUTO)));
+  const int cus = env_device_cus(SFW_DEFAULT_CUS);  // host only: no device to ask
+  const std::vector<int> steps = choose_levels(pc, T, num_steps, static_cast<double>(sfw_samples_per_wave(n_agents, T, SFW_K2_AUTO, cus)), cus);
   *n_levels = static_cast<int32_t>(steps.size());
   for (size_t l = 0; l < steps.size() && l < static_cast<size_t>(cap); ++l) {
     level_ends[l] = steps[l];
@@ -1296,7 +1329,8 @@ int sfw_plan_row_blocks(const double *linvels, int32_t nv, const double *angvels
   if (!all_finite(linvels, static_cast<size_t>(nv)) || !all_finite(angvels, static_cast<size_t>(nw))) return SFW_ERR_INVALID_ARG;
   const std::vector<double> lin(linvels, linvels + nv), ang(angvels, angvels + nw);
   std::vector<int32_t> cuts;
-  plan_row_blocks(lin, ang, vx0, vtheta0, acc_x, acc_theta, sim_time / num_steps, num_steps, n_agents, R, SFW_K2_AUTO, cuts);
+  plan_row_blocks(lin, ang, vx0, vtheta0, acc_x, acc_theta, sim_time / num_steps, num_steps, n_agents, R, SFW_K2_AUTO,
+                  env_device_cus(SFW_DEFAULT_CUS), cuts);
   std::memcpy(row0, cuts.data(), sizeof(int32_t) * (static_cast<size_t>(R) + 1));
   return SFW_OK;
 }
@@ -1318,7 +1352,7 @@ int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out) {
     if (chunk > T) chunk = T;
     out->chunks = chunk > 0 ? static_cast<int32_t>((T + chunk - 1) / chunk) : 0;
   }
-  out->organisation = sfw_social_organisation(h->st_A, out->chunks > 0 ? (T + out->chunks - 1) / out->chunks : T, h->st_O, h->k2_form);
+  out->organisation = sfw_social_organisation(h->st_A, out->chunks > 0 ? (T + out->chunks - 1) / out->chunks : T, h->st_O, h->k2_form, h->n_cu);
   return SFW_OK;
 }
 
@@ -1438,7 +1472,10 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
     e = sfw_launch_rollout(L, h->stream);
   }
   std::vector<int32_t> coll(n, -1);
-  if (e == hipSuccess && h->launched)
+  // a capturing launch wrote its contact steps into the capture buffer, not into coll_step (this path is then only reached
+  // when the step count changed since: cap_S != S): the contact steps come from the re-integration below instead
+  const bool coll_elsewhere = h->launched && h->captured;
+  if (e == hipSuccess && h->launched && !coll_elsewhere)
     e = hipMemcpyAsync(coll.data(), h->coll_step.p + first, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess)
     e = hipMemcpyAsync(n_points, h->n_points.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream);
@@ -1452,7 +1489,7 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
   // contact steps from that run.
   bool rejected = false;
   for (size_t i = 0; i < n && !rejected; ++i) rejected = n_points[i] < S;
-  if (rejected && h->st_A > 1) {
+  if ((rejected || coll_elsewhere) && h->st_A > 1) {
     if (int rc = check_lds(h, count)) return rc;
     SFW_HIP(h, h->pts_coll.reserve(n));
     sfw_launch L;
@@ -1811,13 +1848,13 @@ int sfw_multi_score_grid(sfw_multi_handle m, const sfw_robot_state *rs, const do
     const int S = num_steps_of(h0->params);
     const bool sharing = h0->prefix_env.empty() || h0->prefix_env[0] != 0;
     plan_row_blocks(m->lin, m->ang, rs->vx, rs->vtheta, args->acc_x, args->acc_theta, h0->params.sim_time / S, S, sharing ? h0->A : 0, R,
-                    h0->k2_form, m->row0);
+                    h0->k2_form, h0->n_cu, m->row0);
   }
   // (0) what is the same for every rank, once: the agent set must fit a wave's LDS for every rank's item count
   // before anything is launched anywhere, and the classes of the column axis (every rank scores all nw columns)
   for (int r = 0; r < R; ++r) {
     const int64_t items = static_cast<int64_t>(m->row0[static_cast<size_t>(r) + 1] - m->row0[static_cast<size_t>(r)]) * nw;
-    if (items > 0 && h0->A > 0 && sfw_social_lds_bytes(h0->A, h0->O, h0->NG, h0->n_grp_mem, items, h0->k2_form) > 160 * 1024)
+    if (items > 0 && h0->A > 0 && sfw_social_lds_bytes(h0->A, h0->O, h0->NG, h0->n_grp_mem, items, h0->k2_form, h0->n_cu) > 160 * 1024)
       return mfail(m, SFW_ERR_UNSUPPORTED, "agent/obstacle set does not fit the 160 KiB LDS of one CU");
   }
   axis_classes cols;

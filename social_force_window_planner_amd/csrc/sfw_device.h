@@ -18,6 +18,11 @@
 #define SFW_SIGN_OF_ZERO 0
 #endif
 
+// Device shape the launch heuristics default to (a whole MI355X: 256 compute units in 8 XCDs of 32); a handle reads its
+// device's own (hipDeviceProp_t.multiProcessorCount) and carries it into every launch (sfw_launch.n_cu / n_xcd).
+#define SFW_DEFAULT_CUS 256
+#define SFW_CUS_PER_XCD 32
+
 // Per-sample status written by the rollout kernel.
 enum : int32_t { SFW_ST_VALID = 0, SFW_ST_INVALID = 1, SFW_ST_SKIPPED = 2 };
 
@@ -54,6 +59,7 @@ struct sfw_derived {
   sfw_force_k<double> d;
   sfw_force_k<float> f;
   double f_desired, inv_tau, rr, inv_O;
+  int32_t obs_tasks, pad_;  // flat K2, laser-point pass: 1 = (agent, segment) tasks over all lanes, 0 = one lane per agent
 };
 
 // Shared-prefix rollout (K2).  Under the acceleration limits the robot's first P steps are
@@ -119,6 +125,7 @@ struct sfw_launch {
   int32_t resume;                // 1: start from in_state records instead of the initial agents
   int32_t force_alive;           // 1: K2 also integrates samples K1 rejected on the costmap (point dumps only)
   int32_t k2_form;               // SFW_K2_AUTO / _REGISTER / _FLAT: which organisation of a K2 wave (sfw_set_k2_form)
+  int32_t n_cu, n_xcd;           // compute units / XCDs of the device (organisation thresholds, XCD-contiguous block order)
   int32_t n_cls, n_col_cls;      // PREFIX: classes of this level, its column classes
   const int32_t *row_rep;        // PREFIX [row classes]  chunk-local row whose robot records represent the class
   const int32_t *col_rep;        // PREFIX [n_col_cls]    column likewise
@@ -184,9 +191,10 @@ hipError_t sfw_launch_key_table(const sfw_sel *sel, double *table, int r, int R,
 int64_t sfw_pair_table_entries(int A);
 hipError_t sfw_launch_pair_table(uint16_t *tab, int A, hipStream_t stream);
 // Samples handled by one wave of the social kernel for A agents (form: SFW_K2_*).
-int sfw_samples_per_wave(int A, int64_t T, int form);
-size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T, int form);
+// (cus: compute units of the device, sfw_launch.n_cu)
+int sfw_samples_per_wave(int A, int64_t T, int form, int cus);
+size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T, int form, int cus);
 // SFW_ORG_* of a K2 launch over T items
-int sfw_social_organisation(int A, int64_t T, int O, int form);
+int sfw_social_organisation(int A, int64_t T, int O, int form, int cus);
 
 #endif  // SFW_DEVICE_H_

@@ -31,6 +31,8 @@
 #include "sfw_device.h"
 #include "sfw_math.h"
 
+#include <type_traits>
+
 #include <math.h>
 #include <stdlib.h>
 #include <cmath>
@@ -442,11 +444,12 @@ template <> struct tiny_of<float> { static constexpr float v = 1e-30f; };
 // to run on XCD b % 8 — used for locality only).  Consecutive sample groups share
 // 128-byte lines of the K1->K2 robot-step table (4 records per line); mapping
 // XCD x to the contiguous range [x*q + min(x,r), ...) of groups makes the blocks
-// that share a line hit the same L2.  Bijective for any grid size.
-__device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned n) {
-  constexpr unsigned NX = 8;
-  const unsigned x = b % NX, k = b / NX;
-  const unsigned q = n / NX, r = n % NX;
+// that share a line hit the same L2.  Bijective for any grid size and any XCD count
+// (nx = sfw_launch.n_xcd: 8 on a whole MI355X, 1 on a CPX partition — the identity).
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned n, unsigned nx) {
+  nx = nx ? nx : 1u;
+  const unsigned x = b % nx, k = b / nx;
+  const unsigned q = n / nx, r = n % nx;
   return x * q + (x < r ? x : r) + k;
 }
 
@@ -619,11 +622,15 @@ __device__ __forceinline__ void desired_force(const agent_consts &k, double px, 
 // into OBS_SEG = 16 consecutive segments of L = ceil(O / 16) points; a segment's terms are added in point order
 // starting from 0, the segment sums are added in segment order.  The register-resident form runs the segments
 // one after the other on the agent's lane (every lane owns an agent there); the flat form makes every (agent, segment)
-// pair a task and walks the tasks 64 at a time — 4 agents x 16 segments per round — whatever the crowd size: 51 agents
-// are 13 rounds of 45 points of a 720-point scan = 585 evaluations per lane where one lane per agent ran 720 on 51 of
-// the 64 lanes (round 3's form above 48 agents; 8 segments until round 3).
+// pair a task and walks the tasks 256 at a time — 16 agents x 16 segments per round, four agents per lane — whatever the
+// crowd size: with 51 agents a lane evaluates 3 x 4 + 1 agents on its 45 points of a 720-point scan = 585 evaluations where
+// one lane per agent ran 720 on 51 of the 64 lanes (round 3's form above 48 agents; 8 segments until round 3).
 constexpr int OBS_SEG = 16;
-constexpr int OBS_AGENTS_PER_ROUND = WAVE / OBS_SEG;
+constexpr int OBS_AGENT_LANES = WAVE / OBS_SEG;  // flat form: 4 lanes per segment, each with its own agents
+#ifndef SFW_OBS_KA
+#define SFW_OBS_KA 4
+#endif
+constexpr int OBS_AGENTS_PER_LANE = SFW_OBS_KA;  // ... up to four per round of tasks: 16 agents x 16 segments per round
 // The points a WAVE-UNIFORM loop reads come straight from global memory through the scalar cache (obs_global: the array
 // as a constant-address-space pointer, so that the loads are s_load and cost neither LDS space nor VALU/VMEM issue);
 // the flat form's task loop, whose lanes walk 16 different segments, reads them with per-lane vector loads (the scan is a
@@ -635,23 +642,57 @@ __device__ __forceinline__ obs_global_ptr obs_global(const double *obstacles) {
 }
 __device__ __forceinline__ double2 obs_point(const double2 *obs, int o) { return obs[o]; }
 __device__ __forceinline__ double2 obs_point(obs_global_ptr obs, int o) { return double2{obs[2 * o], obs[2 * o + 1]}; }
+#ifndef SFW_OBS_UNROLL_SCALAR
+#define SFW_OBS_UNROLL_SCALAR 4  // points per s_load group of a wave-uniform loop (4: one s_load_dwordx16)
+#endif
+// one (agent, point) term: a += exp(-|p - q| / sigma) / |p - q| * (p - q)
+template <typename R>
+__device__ __forceinline__ void obstacle_term(const sfm_consts<R> &k, double2 q, double px, double py, R nis, R &ax, R &ay) {
+  using namespace sfwm;
+  const R mx = R(px - q.x), my = R(py - q.y);
+  R rm, mn;
+  rsqrt_sqrt(fma(mx, mx, fma(my, my, tiny_of<R>::v)), rm, mn);
+  const R e = exp2_scaled(k.pc, mn, nis) * rm;
+  ax = fma(e, mx, ax);
+  ay = fma(e, my, ay);
+}
+// nis: -log2(e) / sigma in a VGPR (vgpr_const; the range reduction's first fma also reads the shift constant, and a VOP3
+// instruction takes one scalar operand)
 template <typename R, typename ObsPtr>
 __device__ __forceinline__ void obstacle_segment(const sfm_consts<R> &k, ObsPtr obs, int o_begin, int o_end,
-                                                 double px, double py, R neg_l2e_inv_sigma, R &ax, R &ay) {
-  using namespace sfwm;
+                                                 double px, double py, R nis, R &ax, R &ay) {
   ax = R(0);
   ay = R(0);
-  // in a VGPR: the range reduction's first fma also reads the shift constant, and a VOP3 instruction takes one scalar operand
-  const R nis = vgpr_const(neg_l2e_inv_sigma);
-#pragma unroll 4
-  for (int o = o_begin; o < o_end; ++o) {
-    const double2 q = obs_point(obs, o);
-    const R mx = R(px - q.x), my = R(py - q.y);
-    R rm, mn;
-    rsqrt_sqrt(fma(mx, mx, fma(my, my, tiny_of<R>::v)), rm, mn);
-    const R e = exp2_scaled(k.pc, mn, nis) * rm;  // exp(-|md| / sigma) / |md|
-    ax = fma(e, mx, ax);
-    ay = fma(e, my, ay);
+#pragma unroll SFW_OBS_UNROLL_SCALAR
+  for (int o = o_begin; o < o_end; ++o) obstacle_term<R>(k, obs_point(obs, o), px, py, nis, ax, ay);
+}
+// The same segment for NJ agents at once (the flat form's task loop): a point is loaded ONCE per lane — a per-lane vector
+// load, the lanes of a wave walk 16 different segments — and meets the lane's NJ agents.  With one agent per lane the
+// vector memory pipe, not the VALU, set the pace of a 720-point scan (one 16-byte load per 28 issue slots and lane).
+// Every (agent, segment) sum is formed in point order as in obstacle_segment: bit-identical.
+template <typename R, int NJ>
+__device__ __forceinline__ void obstacle_segment_multi(const sfm_consts<R> &k, const double2 *obs, int o_begin, int o_end,
+                                                       const double *px, const double *py, R neg_l2e_inv_sigma, R *ax, R *ay) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) ax[j] = ay[j] = R(0);
+  const R nis = neg_l2e_inv_sigma;
+  auto terms = [&](const double2 q) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) obstacle_term<R>(k, q, px[j], py[j], nis, ax[j], ay[j]);
+  };
+  // One point ahead, two register sets in turn: the load of the next point is in flight while a point meets the lane's
+  // agents (a lone wave — a control cycle's — otherwise sits out an L1 round trip per point).  The index is clamped to the
+  // segment, so no lane reads past its points; a clamped (repeated) point is loaded and never evaluated.
+  const int last = o_end - 1;
+  if (o_begin < o_end) {
+    double2 qa = obs[o_begin];
+#pragma unroll 1
+    for (int o = o_begin; o < o_end; o += 2) {
+      const double2 qb = obs[min(o + 1, last)];
+      terms(qa);
+      qa = obs[min(o + 2, last)];
+      if (o + 1 < o_end) terms(qb);
+    }
   }
 }
 // what an agent's sum over the points is multiplied with: k exp(radius / sigma) / O
@@ -659,23 +700,100 @@ template <typename R>
 __device__ __forceinline__ double obstacle_scale(const sfm_consts<R> &k, const agent_consts &c, double radius) {
   return static_cast<double>(sfwm::exp2_fast(k.pc, static_cast<R>(fma(radius, c.l2e_inv_sigma, c.l2_f_obstacle)))) * c.inv_O;
 }
-// all sixteen segments on one lane
-template <typename R, typename ObsPtr>
-__device__ __forceinline__ void obstacle_force(const sfm_consts<R> &k, const agent_consts &c, ObsPtr obs,
-                                               double px, double py, double radius, double &fx, double &fy) {
+// Four points = one s_load_dwordx16 into 16 SGPRs, issued and awaited by hand: the loads of a wave-uniform pass are
+// software-pipelined ACROSS the segments — while a group of four points is evaluated (4 x 28 issue slots) the next group's
+// load is in flight, also when that group opens the next segment.  Left to the compiler every s_load was followed at once
+// by s_waitcnt lgkmcnt(0) (scalar loads return out of order: any use needs the counter at zero), so a lone wave — a control
+// cycle, a coarse shared-prefix level — sat out the scalar-cache latency once per four points, sixteen times per agent and
+// step for a 64-point scan.  Two register sets alternate; a set is only read after the wait that follows its load (the asm
+// operands say so: the wait "modifies" the set).
+typedef double obs_group __attribute__((ext_vector_type(8)));  // x0 y0 x1 y1 x2 y2 x3 y3
+__device__ __forceinline__ void obs_group_issue(obs_group &g, obs_global_ptr p) {
+  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(g) : "s"(p));
+}
+__device__ __forceinline__ void obs_group_wait(obs_group &g) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g)); }
+
+// all sixteen segments on one lane: the agent's raw sums (tx, ty) and the factor they are to be multiplied with.  The
+// callers form the force as ONE explicit fma per component, acc = fma(t, scale, acc), in both organisations: written as a
+// product followed by +=, whether the two are contracted into an fma is the compiler's choice per call site, and the
+// organisations stopped being bit-identical the day it chose differently.
+// The points array is readable 48 bytes past its last point (sfw_set_agents pads it): the last group of a segment is
+// loaded whole and evaluated up to the segment's end.
+// PIPELINED = false: the compiler's loop (s_load, wait, four terms).  The register form, which only runs with several
+// waves per SIMD, uses it: there the other waves cover the load and the hand-pipelined loop's extra scalar bookkeeping
+// costs 5-7 % (cfg2 + 240 points K2 3.33 -> 3.56 ms, same-session).  Same sums in the same order either way.
+template <typename R, bool PIPELINED>
+__device__ __forceinline__ void obstacle_sums(const sfm_consts<R> &k, const agent_consts &c, obs_global_ptr obs, double px,
+                                              double py, double radius, double &tx_out, double &ty_out, double &scale) {
   const int O = c.O, L = (O + OBS_SEG - 1) / OBS_SEG;
-  const R nis = static_cast<R>(-c.l2e_inv_sigma);
-  R tx = R(0), ty = R(0);
-  for (int seg = 0; seg < OBS_SEG; ++seg) {
-    const int b = min(seg * L, O), e = min(b + L, O);  // the last segments of a short scan are empty: they add +0
-    R ax, ay;
-    obstacle_segment<R, ObsPtr>(k, obs, b, e, px, py, nis, ax, ay);
-    tx = seg == 0 ? ax : tx + ax;
-    ty = seg == 0 ? ay : ty + ay;
+  const R nis = sfwm::vgpr_const(static_cast<R>(-c.l2e_inv_sigma));
+  R tx = R(0), ty = R(0);  // the segment sums are added to +0 in segment order (the flat form's reduction does the same)
+  R ax = R(0), ay = R(0);
+  if constexpr (!PIPELINED) {
+    for (int b = 0; b < O; b += L) {  // ceil(O / L) <= 16 segments
+      obstacle_segment<R, obs_global_ptr>(k, obs, b, min(b + L, O), px, py, nis, ax, ay);
+      tx += ax;
+      ty += ay;
+    }
+    tx_out = static_cast<double>(tx);
+    ty_out = static_cast<double>(ty);
+    scale = obstacle_scale<R>(k, c, radius);
+    return;
   }
-  const double sc = obstacle_scale<R>(k, c, radius);
-  fx = static_cast<double>(tx) * sc;
-  fy = static_cast<double>(ty) * sc;
+  // one group: `cnt` points of set g, then — if the segment ends with it — the segment's sum joins the total
+  auto eval = [&](const obs_group &g, int cnt, bool seg_done) {
+    if (cnt == 4) {
+      obstacle_term<R>(k, double2{g.s0, g.s1}, px, py, nis, ax, ay);
+      obstacle_term<R>(k, double2{g.s2, g.s3}, px, py, nis, ax, ay);
+      obstacle_term<R>(k, double2{g.s4, g.s5}, px, py, nis, ax, ay);
+      obstacle_term<R>(k, double2{g.s6, g.s7}, px, py, nis, ax, ay);
+    } else {
+      asm volatile("" ::: "memory");  // not the same code as above: the compiler must not merge the first term of the two paths
+      obstacle_term<R>(k, double2{g.s0, g.s1}, px, py, nis, ax, ay);  // (the four terms of a full group are to be interleaved)
+      if (cnt > 1) obstacle_term<R>(k, double2{g.s2, g.s3}, px, py, nis, ax, ay);
+      if (cnt > 2) obstacle_term<R>(k, double2{g.s4, g.s5}, px, py, nis, ax, ay);
+    }
+    if (seg_done) {
+      tx += ax;
+      ty += ay;
+      ax = R(0);
+      ay = R(0);
+    }
+  };
+  // the group after the one at o of the segment ending at e: (o, e) advance, false when there is none
+  auto advance = [&](int &o, int &e) {
+    o += 4;
+    if (o >= e) {  // next segment
+      o = e;
+      e = min(e + L, O);
+    }
+    return o < O;
+  };
+  if (O > 0) {
+    int o = 0, e = min(L, O);
+    obs_group ga, gb;
+    obs_group_issue(ga, obs);
+    for (;;) {
+      int o2 = o, e2 = e;
+      const bool more = advance(o2, e2);
+      obs_group_wait(ga);
+      if (more) obs_group_issue(gb, obs + 2 * o2);
+      eval(ga, min(4, e - o), o + 4 >= e);
+      if (!more) break;
+      o = o2;
+      e = e2;
+      const bool more2 = advance(o2, e2);
+      obs_group_wait(gb);
+      if (more2) obs_group_issue(ga, obs + 2 * o2);
+      eval(gb, min(4, e - o), o + 4 >= e);
+      if (!more2) break;
+      o = o2;
+      e = e2;
+    }
+  }
+  tx_out = static_cast<double>(tx);
+  ty_out = static_cast<double>(ty);
+  scale = obstacle_scale<R>(k, c, radius);
 }
 
 // LDS map of one wave.  Agent state lives in PLANES of `cap` doubles each — px, py, vx, vy, the force
@@ -695,9 +813,11 @@ struct lds_layout {
   sfw_agent_const *ac;  // the per-agent launch constants as they sit in global memory (48 B records: one address
                         // register per agent reaches every field through the DS offset field)
   double *swp;
-  double2 *opart;       // flat form with laser points: the 64 lanes' partial obstacle sums of one round of tasks
+  double2 *opart;       // flat form with laser points: the 64 lanes' segment sums of two of their agents ([2][64])
   double *wr;           // flat form with laser points: the robot's social-work term waiting for its obstacle part [0] and
                         // the two components of that part [1], [2]
+  double *oscale;       // flat form with laser points: obstacle_scale of every agent, formed once per launch (the reduction
+                        // of a round of tasks would otherwise wait for the agent's radius from global memory every time)
   int *hasgoal, *dead, *grp, *goff, *gmem;  // hasgoal: register form (one int per 8-byte cell)
   unsigned char *hasgoal8;  // flat form: one byte per agent (crowds of 129..255 agents are LDS-bound in occupancy)
   int hg_stride;        // ints between two slots' hasgoal words (see hg())
@@ -729,8 +849,9 @@ struct lds_layout {
       fcy = reinterpret_cast<double *>(take(plane));
       rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * 2));
       swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
-      opart = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? 64 : 0)));
+      opart = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? 2 * 64 : 0)));
       wr = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? 4 : 0)));
+      oscale = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? A : 0)));
       hasgoal8 = reinterpret_cast<unsigned char *>(take(static_cast<size_t>(GA)));
       hasgoal = nullptr;
       hg_stride = 1;
@@ -739,6 +860,7 @@ struct lds_layout {
       fcx = fcy = nullptr;
       opart = nullptr;
       wr = nullptr;
+      oscale = nullptr;
       hasgoal = reinterpret_cast<int *>(take(plane));
       hasgoal8 = nullptr;
       hg_stride = 2;
@@ -1079,7 +1201,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   const int GA = G * A;
   const int NG = GROUPS ? L.NG : 0;  // GROUPS=false instantiation: no group code, lean register budget
   const lds_layout s(smem, A, CAP, GA, G, O, NG, GROUPS ? L.n_grp_mem : 0, true, false);
-  const int64_t first_local = static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x)) * G;
+  const int64_t first_local = static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd))) * G;
   const int64_t remain = item_count(L) - first_local;
   const int Gn = remain < G ? static_cast<int>(remain) : G;
   const int step_begin = L.step_begin, step_end = L.step_end;
@@ -1155,10 +1277,10 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
           const agent_k ak = agent_k_lds(s, i);
           desired_force(c0, px, py, vx, vy, hg != 0, ak.gx, ak.gy, ak.gr, ak.dv, fx[r], fy[r]);
           if (O > 0) {
-            double ox, oy;
-            obstacle_force<R>(k0, c0, obs_global(L.obstacles), px, py, ak.rad, ox, oy);
-            fx[r] += ox;
-            fy[r] += oy;
+            double tx, ty, sc;
+            obstacle_sums<R, false>(k0, c0, obs_global(L.obstacles), px, py, ak.rad, tx, ty, sc);
+            fx[r] = fma(tx, sc, fx[r]);
+            fy[r] = fma(ty, sc, fy[r]);
           }
         }
         if (L.agent_rest) {  // pairs at exact relative rest in the handed-over state (robot included)
@@ -1350,19 +1472,19 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
       for (int r = 0; r < NS; ++r)
         if (ok_[r] && lds_at<int>(smem, off::DEAD + g4_[r]) == 0) {
           const uint32_t io = io_[r];
-          double ox, oy;
-          obstacle_force<R>(k, c, obs_global(late_args()->obstacles), lds_at<double>(smem, io), lds_at<double>(smem, io + PY),
-                            lds_at<double>(smem, ci_[r] + 32u), ox, oy);
+          double tx, ty, sc;
+          obstacle_sums<R, false>(k, c, obs_global(late_args()->obstacles), lds_at<double>(smem, io), lds_at<double>(smem, io + PY),
+                           lds_at<double>(smem, ci_[r] + 32u), tx, ty, sc);
           if (i_[r] == 0) {
-            sw[r] += lds_at<double>(smem, io + off::SW) + fast_norm(ox, oy);
+            sw[r] += lds_at<double>(smem, io + off::SW) + fast_norm(tx * sc, ty * sc);
             const sfw_robot_step r2 = lds_at<sfw_robot_step>(smem, off::RSB + 8u * g4_[r]);
             lds_at<double>(smem, io) = r2.x;
             lds_at<double>(smem, io + PY) = r2.y;
             lds_at<double>(smem, io + VX) = r2.vx;
             lds_at<double>(smem, io + VY) = r2.vy;
           } else {
-            fx[r] += ox;
-            fy[r] += oy;
+            fx[r] = fma(tx, sc, fx[r]);
+            fy[r] = fma(ty, sc, fy[r]);
           }
         }
     }
@@ -1477,8 +1599,8 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
   (void)FCX;
   (void)FCY;
   const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, GROUPS, true);
-  const int64_t first_local = xcd_contiguous(blockIdx.x, gridDim.x);
-  const sfm_consts<R> k = make_consts<R, true>(L);
+  const int64_t first_local = xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd));
+  const sfm_consts<R> k0 = make_consts<R, true>(L);  // the prologue's; every step builds its own (below)
   constexpr bool F32 = sizeof(R) == 4;
   const int step_begin = L.step_begin, step_end = L.step_end;
   if (!stage_wave<GROUPS, GROUPS>(L, s, lane, 1, 1, first_local)) {
@@ -1487,7 +1609,12 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     return;
   }
   clock_probe(0);
-  const int64_t rsample = robot_sample_of_item(L, first_local);
+  // wave-uniform, but formed from table loads: made scalar explicitly (as a VGPR pair it is held — in scratch, once the
+  // laser-point pass needs the registers — across the whole rollout for the two lanes that fetch the robot records)
+  const int64_t rsample_v = robot_sample_of_item(L, first_local);
+  const int64_t rsample = static_cast<int64_t>(
+      (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rsample_v >> 32)))) << 32) |
+      static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rsample_v))));
 
   if (L.resume) {  // resume from the record of the item's (parent) class
     const sfw_cls_agent *rec = L.in_state + source_class_of_item(L, first_local) * A;
@@ -1519,10 +1646,10 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       if (sl != 0) {
         desired_force(c0, px, py, vx, vy, c.has_goal != 0, c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity, fx, fy);
         if (O > 0) {
-          double ox, oy;
-          obstacle_force<R>(k, c0, obs_global(L.obstacles), px, py, c.radius, ox, oy);
-          fx += ox;
-          fy += oy;
+          double tx, ty, sc;
+          obstacle_sums<R, true>(k0, c0, obs_global(L.obstacles), px, py, c.radius, tx, ty, sc);
+          fx = fma(tx, sc, fx);
+          fy = fma(ty, sc, fy);
         }
       }
       if (L.agent_rest) {  // pairs at exact relative rest in the handed-over state (robot included)
@@ -1534,12 +1661,16 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       s.fjx[sl] = s.fjy[sl] = 0.0;
     }
   }
+  if (O > 0) {
+    const agent_consts c0 = load_agent_consts(late_args(), F32);
+    for (int sl = lane; sl < A; sl += WAVE) s.oscale[sl] = obstacle_scale<R>(k0, c0, L.agent_c[sl].radius);
+  }
   for (int sl = A + lane; sl < cap; sl += WAVE) {  // the dummy slots: finite state, accumulators nobody reads
     s.px[sl] = s.py[sl] = s.vx[sl] = s.vy[sl] = 0.0;
     s.fcx[sl] = s.fcy[sl] = s.fjx[sl] = s.fjy[sl] = 0.0;
   }
   __syncthreads();
-  auto add_group_forces = [&](const agent_consts &c) {
+  auto add_group_forces = [&](const sfm_consts<R> &k, const agent_consts &c) {
     for (int q = lane; q < NG; q += WAVE) s.gcen[q] = double2{0.0, 0.0};
     __syncthreads();
     for (int sl = lane; sl < A; sl += WAVE)
@@ -1557,7 +1688,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     __syncthreads();
   };
   if constexpr (GROUPS) {
-    if (!L.resume) add_group_forces(load_agent_consts(late_args(), F32));  // a class record's force already has them
+    if (!L.resume) add_group_forces(k0, load_agent_consts(late_args(), F32));  // a class record's force already has them
   }
 
   const int P = A * (A - 1) / 2;  // unordered pairs
@@ -1571,8 +1702,10 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     if (lane == 0) s.rsb[buf] = rstep[static_cast<int64_t>(st) * stride + rsample];
     return;
 #endif
-    if (lane < 2) {
-      const char *src = reinterpret_cast<const char *>(rstep + static_cast<int64_t>(st) * stride + rsample) + 16 * lane;
+    int l2 = lane;
+    asm volatile("" : "+v"(l2));  // opaque: 16 * lane is formed here, not held across the rollout
+    if (l2 < 2) {
+      const char *src = reinterpret_cast<const char *>(rstep + static_cast<int64_t>(st) * stride + rsample) + 16 * l2;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                        (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(s.rsb + buf)), 16,
                                        0, 0);
@@ -1584,7 +1717,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
   double abl_ix = s.px[lane < A ? lane : 0], abl_iy = s.py[lane < A ? lane : 0], abl_fx = 0.0, abl_fy = 0.0;
 #endif
   // one pair per lane: both agents from LDS, the force into both agents' accumulators
-  auto pair_at = [&](uint32_t io, uint32_t jo) {
+  auto pair_at = [&](const sfm_consts<R> &k, uint32_t io, uint32_t jo) {
     R qx, qy;
     if constexpr (CAP > 0) {
       double pix, piy, vix, viy, pjx, pjy, vjx, vjy;
@@ -1625,6 +1758,10 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
   };
 
   for (int step = step_begin; step < step_end; ++step) {
+    // The pair term's constants pinned to VGPRs (five force constants, two leading polynomial coefficients: 14 registers)
+    // are (re)built per step: they are opaque to the compiler, so held across the rollout they also sit through the
+    // laser-point pass, whose four-agents-per-lane loop needs the registers.
+    const sfm_consts<R> k = make_consts<R, true>(late_args());
     if (n_it > 0) {
       uint32_t ia, ja, ib, jb;
       load_pair_entries(tab_i, tab_j, lane_off, ia, ja);
@@ -1633,14 +1770,14 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       for (; left >= 2; left -= 2, ti += 2 * WAVE, tj += 2 * WAVE) {
         wait_pair_entries(ia, ja);  // also covers the robot record issued a step ago
         load_pair_entries(ti, tj, lane_off, ib, jb);
-        pair_at(ia, ja);
+        pair_at(k, ia, ja);
         wait_pair_entries(ib, jb);
         if (left > 2) load_pair_entries(ti + WAVE, tj + WAVE, lane_off, ia, ja);
-        pair_at(ib, jb);
+        pair_at(k, ib, jb);
       }
       if (left == 1) {
         wait_pair_entries(ia, ja);
-        pair_at(ia, ja);
+        pair_at(k, ia, ja);
       }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1700,36 +1837,80 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       s.fjy[sl] = 0.0;
     }
     if (with_obs) {
-      // Obstacle term: the robot at its pre-step position (Wr's obstacle part), a person at its new position.  Every
-      // (agent, segment) pair is a task; the wave walks them 64 at a time, 4 agents x 16 segments per round (same sums in
-      // the same order as obstacle_force).  Lane l: segment l / 4 of agent a0 + l % 4 — four neighbouring lanes read the
-      // same point — the points through per-lane loads from global memory (L1).
+      // Obstacle term: the robot at its pre-step position (Wr's obstacle part), a person at its new position.
       __syncthreads();
-      const int Lseg = (c.O + OBS_SEG - 1) / OBS_SEG, seg = lane >> 2, sub = lane & (OBS_AGENTS_PER_ROUND - 1);
-      const int ob = min(seg * Lseg, c.O), oe = min(ob + Lseg, c.O);
-      const R nis = static_cast<R>(-c.l2e_inv_sigma);
-      const double2 *const pts = reinterpret_cast<const double2 *>(La->obstacles);
-      const double *const part = reinterpret_cast<const double *>(s.opart);
-      for (int a0 = 0; a0 < A; a0 += OBS_AGENTS_PER_ROUND) {
-        const int a = a0 + sub;
-        R ax = R(0), ay = R(0);
-        if (a < A) obstacle_segment<R, const double2 *>(k, pts, ob, oe, s.px[a], s.py[a], nis, ax, ay);
-        s.opart[lane] = double2{static_cast<double>(ax), static_cast<double>(ay)};
-        __syncthreads();
-        // the sixteen segment sums in segment order: component x on the agent's first lane, y on its second
-        if (a < A && seg < 2) {
-          R t = static_cast<R>(part[2 * sub + seg]);
+      if (La->k.obs_tasks) {
+        // Every (agent, segment) pair is a task; the wave walks them 256 at a time, 16 agents x 16 segments per round (same
+        // sums in the same order as obstacle_sums).  Lane l: segment l / 4 of the agents a0 + l % 4 + {0, 4, 8, 12} — four
+        // neighbouring lanes read the same point — the points through per-lane loads from global memory (L1), one load per
+        // point and lane for up to four agents (obstacle_segment_multi).
+        const int Lseg = (c.O + OBS_SEG - 1) / OBS_SEG, seg = lane >> 2, sub = lane & (OBS_AGENT_LANES - 1);
+        const int ob = min(seg * Lseg, c.O), oe = min(ob + Lseg, c.O);
+        const R nis = sfwm::vgpr_const(static_cast<R>(-c.l2e_inv_sigma));
+        const double2 *const pts = reinterpret_cast<const double2 *>(La->obstacles);
+        const double *const part = reinterpret_cast<const double *>(s.opart);
+        constexpr int KA = OBS_AGENTS_PER_LANE;
+        for (int a0 = 0; a0 < A; a0 += OBS_AGENT_LANES * KA) {
+          // lane (seg, sub) takes agents a0 + sub + 4 j, j < nj (wave-uniform; a lane past the last agent works on zeros)
+          const int nj = min(KA, (A - a0 + OBS_AGENT_LANES - 1) / OBS_AGENT_LANES);
+          double pxj[KA], pyj[KA];
+          R axj[KA + 1], ayj[KA + 1];  // (+1: the reduction below takes the slots in twos)
 #pragma unroll
-          for (int q = 1; q < OBS_SEG; ++q) t += static_cast<R>(part[2 * (sub + OBS_AGENTS_PER_ROUND * q) + seg]);
+          for (int j = 0; j < KA; ++j) {
+            const int a = a0 + sub + OBS_AGENT_LANES * j;
+            pxj[j] = a < A ? s.px[a] : 0.0;
+            pyj[j] = a < A ? s.py[a] : 0.0;
+          }
+#pragma unroll
+          for (int j = 0; j <= KA; ++j) axj[j] = ayj[j] = R(0);
+          switch (nj) {
+            case 1: obstacle_segment_multi<R, 1>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
+            case 2: obstacle_segment_multi<R, 2>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
+            case (KA > 3 ? 3 : -1): obstacle_segment_multi<R, 3>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
+            default: obstacle_segment_multi<R, KA>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
+          }
+          // The sixteen segment sums of an agent are added in segment order by one lane per component: two of the lanes'
+          // agent slots at a time go through LDS (2 KB: what the wave can spare without losing a wave per SIMD at the target
+          // crowd), lane l < 16 sums component l & 1 of agent slot j0 + (l >> 1 & 1) of lane group l >> 2.
+#pragma unroll
+          for (int j0 = 0; j0 < KA; j0 += 2) {
+            if (j0 < nj) {
+              s.opart[lane] = double2{static_cast<double>(axj[j0]), static_cast<double>(ayj[j0])};
+              s.opart[WAVE + lane] = double2{static_cast<double>(axj[j0 + 1]), static_cast<double>(ayj[j0 + 1])};
+              __syncthreads();
+              const int comp = lane & 1, js = (lane >> 1) & 1, gsub = lane >> 2;  // gsub < 4 for lane < 16
+              const int a = a0 + gsub + OBS_AGENT_LANES * (j0 + js);
+              if (lane < 16 && a < A) {
+                const double *const col = part + 2 * (WAVE * js + gsub) + comp;  // segment q of that agent: + 2 * 4 * q
+                R t = R(0);  // + 0 first, as obstacle_sums does; empty segments of a short scan add +0
+#pragma unroll
+                for (int q = 0; q < OBS_SEG; ++q) t += static_cast<R>(col[2 * OBS_AGENT_LANES * q]);
+                const double sc = s.oscale[a];
+                if (a == 0) s.wr[1 + comp] = static_cast<double>(t) * sc;
+                else if (comp == 0) s.fcx[a] = fma(static_cast<double>(t), sc, s.fcx[a]);
+                else s.fcy[a] = fma(static_cast<double>(t), sc, s.fcy[a]);
+              }
+              __syncthreads();
+            }
+          }
+        }
+        if (lane == 0) s.swp[0] += s.wr[0] + fast_norm(s.wr[1], s.wr[2]);
+      } else {
+        // A short scan: the agent's lane runs the sixteen segments itself, the points through the scalar cache (the rounds
+        // of the task loop cost more than they spread; sfw_derive prices both)
+        for (int a = lane; a < A; a += WAVE) {
           const double rad = GROUPS ? s.ac[a].radius : agent_c[a].radius;
-          const double f = static_cast<double>(t) * obstacle_scale<R>(k, c, rad);
-          if (a == 0) s.wr[1 + seg] = f;
-          else if (seg == 0) s.fcx[a] += f;
-          else s.fcy[a] += f;
+          double tx, ty, sc;
+          obstacle_sums<R, true>(k, c, obs_global(La->obstacles), s.px[a], s.py[a], rad, tx, ty, sc);
+          if (a == 0) {
+            s.swp[0] += s.wr[0] + fast_norm(tx * sc, ty * sc);
+          } else {
+            s.fcx[a] = fma(tx, sc, s.fcx[a]);
+            s.fcy[a] = fma(ty, sc, s.fcy[a]);
+          }
         }
         __syncthreads();
       }
-      if (lane == 0) s.swp[0] += s.wr[0] + fast_norm(s.wr[1], s.wr[2]);
       if (lane == 0) {
         s.px[0] = rs.x;
         s.py[0] = rs.y;
@@ -1739,7 +1920,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     }
     __syncthreads();
     if (s.dead[0] != 0) break;
-    if constexpr (GROUPS) add_group_forces(c);
+    if constexpr (GROUPS) add_group_forces(k, c);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a prefetched robot record may still be in flight
   const late_launch Le = late_args();
@@ -1891,7 +2072,7 @@ __global__ void __launch_bounds__(64) sfw_key_table_kernel(const sfw_sel *sel, d
 struct wave_plan { int G; int ns; bool flat; };
 // form: SFW_K2_AUTO, or SFW_K2_REGISTER / SFW_K2_FLAT forced by the caller (sfw_set_k2_form, SFW_FORCE_FLAT in the
 // environment of sfw_create) — honoured wherever the form exists for A (register: 1 <= A <= 128; flat: A >= 2 or O > 0).
-static wave_plan plan_for(int A, int64_t T, int O, int form) {
+static wave_plan plan_for(int A, int64_t T, int O, int form, int cus) {
   if (A <= 0) return wave_plan{1, 1, false};
   const int P = A * (A - 1) / 2;
   const int rows = A / 2;
@@ -1906,18 +2087,19 @@ static wave_plan plan_for(int A, int64_t T, int O, int form) {
     if (c_reg < c_flat) best = reg;
   }
   // ... and a robot alone among laser points: the flat form spreads the points over eight lanes
-  if (T <= (A <= 8 ? 1536 : A <= 12 ? 3072 : 4096) && (A >= 2 || O > 0)) best = flat;
+  // (the item thresholds were measured on 256 compute units and scale with the device: 6 / 12 / 16 items per CU)
+  if (T <= static_cast<int64_t>(A <= 8 ? 6 : A <= 12 ? 12 : 16) * cus && (A >= 2 || O > 0)) best = flat;
   if (form == SFW_K2_FLAT && (A >= 2 || O > 0)) best = flat;
   if (form == SFW_K2_REGISTER && A <= 2 * WAVE) best = reg;
   return best;
 }
 
-int sfw_samples_per_wave(int A, int64_t T, int form) { return plan_for(A, T, 0, form).G; }
+int sfw_samples_per_wave(int A, int64_t T, int form, int cus) { return plan_for(A, T, 0, form, cus).G; }
 
 // SFW_ORG_* of the launch plan_for() picks for T items
-int sfw_social_organisation(int A, int64_t T, int O, int form) {
+int sfw_social_organisation(int A, int64_t T, int O, int form, int cus) {
   if (A <= 0) return SFW_ORG_NONE;
-  const wave_plan pl = plan_for(A, T, O, form);
+  const wave_plan pl = plan_for(A, T, O, form, cus);
   return pl.flat ? SFW_ORG_FLAT : pl.ns == 2 ? SFW_ORG_REGISTER_2 : SFW_ORG_REGISTER_1;
 }
 
@@ -1946,6 +2128,16 @@ void sfw_derive(sfw_launch &L) {
   L.k.inv_tau = 1.0 / p.sfm_relaxation_time;
   L.k.rr = static_cast<double>(static_cast<float>(p.robot_radius) * static_cast<float>(p.robot_radius));  // ref :617
   L.k.inv_O = L.O > 0 ? 1.0 / L.O : 0.0;
+  // Flat form, laser-point pass: (agent, segment) tasks over all 64 lanes, or one lane per agent?  Issue slots per step
+  // (28 per evaluation; a round of the task loop also costs its two reduction phases, ~40 slots each):
+  {
+    const int A = L.A, O = L.O, Lseg = (O + OBS_SEG - 1) / OBS_SEG;
+    const int full = A / (OBS_AGENT_LANES * OBS_AGENTS_PER_LANE), rest = (A % (OBS_AGENT_LANES * OBS_AGENTS_PER_LANE) + OBS_AGENT_LANES - 1) / OBS_AGENT_LANES;
+    const double red = 40.0;
+    const double c_tasks = full * (28.0 * Lseg * OBS_AGENTS_PER_LANE + 2 * red) + (rest ? 28.0 * Lseg * rest + ((rest + 1) / 2) * red : 0.0);
+    const double c_lane = 28.0 * O * ((A + WAVE - 1) / WAVE);
+    L.k.obs_tasks = (O > 0 && c_tasks < c_lane) ? 1 : 0;
+  }
 }
 
 // Capacity (doubles per LDS plane) of the flat kernel for A agents: compile-time 64 / 128 / 256 when A fits with
@@ -1965,8 +2157,8 @@ static size_t lds_bytes_for(const wave_plan &pl, int A, int O, int NG, int n_grp
 
 // Largest LDS allocation any launch of a chunk of T samples may ask for (the prefix phase of the
 // shared-prefix rollout may pick the flat organisation where the chunk itself uses the other).
-size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T, int form) {
-  const size_t a = lds_bytes_for(plan_for(A, T, O, form), A, O, NG, n_grp_mem);
+size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T, int form, int cus) {
+  const size_t a = lds_bytes_for(plan_for(A, T, O, form, cus), A, O, NG, n_grp_mem);
   const size_t b = (A >= 2 || O > 0) ? lds_bytes_for(wave_plan{1, 0, true}, A, O, NG, n_grp_mem) : 0;
   return a > b ? a : b;
 }
@@ -2047,13 +2239,15 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L,
   // organisation-neutral, so every launch picks its own by its item count (measured: forcing the
   // flat form on an under-filled prefix phase at cfg2 — 2024 register-form waves — changes nothing).
   const int64_t items = L.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L.n_cls) : L.chunk_count;
-  const wave_plan pl = plan_for(L.A, items, L.O, L.k2_form);
+  const wave_plan pl = plan_for(L.A, items, L.O, L.k2_form, L.n_cu > 0 ? L.n_cu : SFW_DEFAULT_CUS);
   const unsigned grid = static_cast<unsigned>((items + pl.G - 1) / pl.G);
   const size_t lds = lds_bytes_for(pl, L.A, L.O, L.NG, L.n_grp_mem);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static const bool layout_ok = reg_layout_matches<WAVE>() && reg_layout_matches<2 * WAVE>();
   if (!layout_ok) return hipErrorInvalidValue;
   const bool groups = L.NG > 0;  // at least one agent carries a group id: kernels with the group pass
+  // the register form brings a step's robot records in with ONE lane < 2 G load and keeps REG_DEAD_CAP contact flags
+  if (!pl.flat && pl.G > lds_layout::REG_DEAD_CAP) return hipErrorInvalidValue;
   if (pl.flat) {
     if (8 * (static_cast<int64_t>(L.A) + 1) > 65535 || !L.pair_tab) return hipErrorInvalidValue;  // 16-bit plane offsets
     switch (flat_cap(L.A)) {

@@ -79,6 +79,17 @@ __device__ __forceinline__ float vgpr_const(float c) {
   asm("" : "+v"(c));
   return c;
 }
+// ... materialised HERE, by the asm itself (two v_mov_b32 of literals): for a constant that a kernel rebuilds per step so
+// that it is not held across the passes that do not use it.  (A volatile asm is not hoisted out of the loop it stands in —
+// but handed the constant as a register INPUT, the compiler materialises that input in front of the rollout and, at the
+// register budgets of the K2 kernels, keeps it in scratch.)
+constexpr uint32_t f64_lo(double c) { return static_cast<uint32_t>(__builtin_bit_cast(uint64_t, c)); }
+constexpr uint32_t f64_hi(double c) { return static_cast<uint32_t>(__builtin_bit_cast(uint64_t, c) >> 32); }
+template <uint32_t LO, uint32_t HI> __device__ __forceinline__ double vgpr_literal_here() {
+  uint32_t lo, hi;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(lo), "=v"(hi) : "n"(LO), "n"(HI));
+  return __builtin_bit_cast(double, (static_cast<uint64_t>(hi) << 32) | lo);
+}
 // A VOP3 instruction reads at most one SGPR operand, so the first Horner step fma(c_n, z, c_{n-1}) of a chain
 // with both coefficients in SGPRs costs an extra v_mov_b64 per evaluation: the leading coefficients live in VGPRs.
 struct poly_consts {
@@ -86,10 +97,10 @@ struct poly_consts {
   __device__ __forceinline__ poly_consts() {
 #pragma unroll
     for (int n = 0; n < SFW_ASIN_DEG; ++n) as[n] = sgpr_const(kAsinQ[n]);
-    as[SFW_ASIN_DEG] = vgpr_const(kAsinQ[SFW_ASIN_DEG]);
+    as[SFW_ASIN_DEG] = vgpr_literal_here<f64_lo(kAsinQ[SFW_ASIN_DEG]), f64_hi(kAsinQ[SFW_ASIN_DEG])>();
 #pragma unroll
     for (int n = 0; n < SFW_EXP_DEG; ++n) ex[n] = sgpr_const(kExp2P[n]);
-    ex[SFW_EXP_DEG] = vgpr_const(kExp2P[SFW_EXP_DEG]);
+    ex[SFW_EXP_DEG] = vgpr_literal_here<f64_lo(kExp2P[SFW_EXP_DEG]), f64_hi(kExp2P[SFW_EXP_DEG])>();
   }
 };
 // v_rsq_f64 / v_rcp_f64 deliver ~23 good bits; one Newton step gives ~46.

@@ -125,3 +125,23 @@ def test_row_blocks_of_equal_planned_work():
     assert list(planner.plan_row_blocks(lin[:64], ang[:16], rs, ga, 1.0, 40, 51, 4)) == [0, 16, 32, 48, 64]
     assert list(planner.plan_row_blocks(lin, ang, rs, ga, 1.0, 40, 1, 4)) == [0, 1024, 2048, 3072, 4096]
     assert list(planner.plan_row_blocks(lin[:3], ang, rs, ga, 1.0, 40, 51, 8)) == [0, 0, 0, 1, 1, 1, 2, 2, 3]
+
+
+def test_the_plan_follows_the_device_shape(monkeypatch):
+    """the cost model behind the shared-prefix levels counts the waves the DEVICE holds at once (4 SIMDs per
+    compute unit x 5.5 waves), not those of a 256-CU MI355X: a 32-CU partition (SFW_DEVICE_CUS=32 stands in for
+    hipDeviceProp_t.multiProcessorCount here — host-only planning has no device to ask) fills up with an eighth of the
+    items, so coarse levels stop being 'free' there and the plan changes."""
+    w = syn.WORKLOADS["cfg2"]
+    scene = syn.make_scene(w)
+    args = (scene.linvels, scene.angvels, scene.robot_state[3], scene.robot_state[5], scene.goal_args[0], scene.goal_args[2],
+            w.sim_time, w.n_steps, w.n_people + 1)
+    monkeypatch.delenv("SFW_DEVICE_CUS", raising=False)
+    whole = _plan(*args)
+    monkeypatch.setenv("SFW_DEVICE_CUS", "256")
+    assert _plan(*args) == whole
+    monkeypatch.setenv("SFW_DEVICE_CUS", "32")
+    part = _plan(*args)
+    assert part != whole and len(part[0]) >= 1
+    monkeypatch.setenv("SFW_DEVICE_CUS", "not a number")
+    assert _plan(*args) == whole

@@ -165,3 +165,31 @@ def test_random_scenes_random_levels(hip_mod, seed):
     c, b = _score(hip_mod, scene, p, ",".join(map(str, levels)), goal_args=ga)
     assert _same(ref, c), f"levels {levels}"
     assert b == bref
+
+
+def test_results_do_not_depend_on_the_device_shape(hip_mod, monkeypatch):
+    """a handle scales its launch heuristics — shared-prefix cost model, the item thresholds of the K2
+    organisation, the XCD-contiguous block order — to its device's compute units and XCDs.  Pretending a 32-CU, one-XCD
+    partition (SFW_DEVICE_CUS / SFW_DEVICE_XCDS, read by sfw_create) changes the plan and must leave every cost, sentinel and
+    the selection bit-identical."""
+    for name, nv, nw in (("cfg2", 64, 64), ("cfg2", 128, 128), ("target", 64, 96)):
+        w = dataclasses.replace(syn.WORKLOADS[name], nv=nv, nw=nw)
+        scene = syn.make_scene(w)
+        p = default_params(sim_time=w.sim_time, sim_granularity=w.sim_granularity)
+        monkeypatch.delenv("SFW_DEVICE_CUS", raising=False)
+        monkeypatch.delenv("SFW_DEVICE_XCDS", raising=False)
+        g = hip_mod.HipScorer(p)
+        g.load_scene(scene)
+        c0, b0 = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+        plan0 = g.plan_info()
+        plans = []
+        for cus, xcds in (("32", None), ("32", "3"), ("8", "1")):
+            monkeypatch.setenv("SFW_DEVICE_CUS", cus)
+            if xcds:
+                monkeypatch.setenv("SFW_DEVICE_XCDS", xcds)
+            g2 = hip_mod.HipScorer(p)
+            g2.load_scene(scene)
+            c2, b2 = g2.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+            assert np.array_equal(c0, c2) and b0 == b2, (name, nv, nw, cus, xcds)
+            plans.append(g2.plan_info())
+        assert any(pl != plan0 for pl in plans), (plan0, plans)

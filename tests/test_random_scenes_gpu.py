@@ -87,6 +87,14 @@ def oracle_sensitivity(oracle_mod, scene, p, rs, ga, lin, ang, base, eps=2e-14, 
     return worst
 
 
+# The kernels' own error against the oracle's libm is ~1e-12 relative per force term (exp2 polynomial 1.1e-12, asin 5.4e-14;
+# csrc/sfw_math.h) = 50 x the 2e-14 the probe injects: a scene may exceed 1e-9 by at most that factor over the oracle's OWN
+# response to the probe (round 3 allowed 1e4 x).  Seeds that needed the allowance are collected and bounded below.
+CHAOS_FACTOR = 50.0
+CHAOS_SEEDS_MAX = 2  # of 40 (the 3000-seed sweeps find ~1 % of the scenes in that regime, profiles/r04_parity_sweep.txt)
+_chaotic_seeds = []
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_random_scene(oracle_mod, hip_mod, seed):
     scene, p, rs, ga, lin, ang = _case(seed)
@@ -103,9 +111,17 @@ def test_random_scene(oracle_mod, hip_mod, seed):
         rel = np.abs(gc[v] - oc[v]) / np.maximum(np.abs(oc[v]), 1e-300)
         if rel.max() > 1e-9:  # only legitimate for a chaotic scene: bounded by the oracle's own conditioning
             sens = oracle_sensitivity(oracle_mod, scene, p, rs, ga, lin, ang, oc)
-            assert rel.max() <= 1e4 * sens, f"seed {seed}: max rel err {rel.max():.3e}, oracle response to 2e-14 noise {sens:.3e}"
+            _chaotic_seeds.append((seed, float(rel.max()), sens))
+            print(f"chaotic scene, seed {seed}: max rel err {rel.max():.3e}, oracle response to 2e-14 noise {sens:.3e}")
+            assert rel.max() <= CHAOS_FACTOR * sens, f"seed {seed}: max rel err {rel.max():.3e}, oracle response to 2e-14 noise {sens:.3e}"
     assert gb["index"] == ob["index"] and gb["n_valid"] == ob["n_valid"]
     assert gb["vx"] == ob["vx"] and gb["vtheta"] == ob["vtheta"]
+
+
+def test_random_scene_chaos_allowance_is_rare():
+    """How many of the 40 seeds above needed the chaos allowance (runs after them; printed with pytest -rA)."""
+    print(f"seeds over 1e-9 that took the chaos allowance: {len(_chaotic_seeds)} of 40: {_chaotic_seeds}")
+    assert len(_chaotic_seeds) <= CHAOS_SEEDS_MAX, _chaotic_seeds
 
 
 def _case_standing(seed):

@@ -47,7 +47,7 @@ def main():
             if rel.max() > 1e-9:
                 k = int(np.argmax(rel))
                 sens = gen.oracle_sensitivity(oracle_mod, scene, p, rs, ga, lin, ang, oc)
-                ok = rel.max() <= 1e4 * sens
+                ok = rel.max() <= gen.CHAOS_FACTOR * sens
                 chaotic += ok
                 unexplained += (not ok)
                 print(f"{'chaotic scene' if ok else 'UNEXPLAINED'} seed {seed}: rel {rel.max():.3e} at sample {k}, oracle response to 2e-14 "
@@ -68,7 +68,7 @@ def main():
             bad_sel32 += 1
     print(f"scenes with the lightsfm default parameters (2 of 3): f64 max rel err {worst_default:.3e}")
     print(f"seeds {first}..{first + n - 1}: {n_samples} samples ({n_valid} valid), f64 max rel err {worst64_well:.3e} over the "
-          f"well-conditioned scenes, {chaotic} chaotic scenes (error within 1e4 x the oracle's own response to 2e-14 input noise, worst "
+          f"well-conditioned scenes, {chaotic} chaotic scenes (error within {gen.CHAOS_FACTOR:.0f} x the oracle's own response to 2e-14 input noise, worst "
           f"{worst64:.3e}), {unexplained} unexplained, "
           f"status mismatches {bad_status}, selection mismatches {bad_sel}; f32 mode max rel err {worst32:.3e}, "
           f"selection differs in {bad_sel32} scenes; {time.time() - t0:.0f} s")
