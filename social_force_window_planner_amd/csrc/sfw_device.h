@@ -59,7 +59,9 @@ struct sfw_derived {
   sfw_force_k<double> d;
   sfw_force_k<float> f;
   double f_desired, inv_tau, rr, inv_O;
-  int32_t obs_tasks, pad_;  // flat K2, laser-point pass: 1 = (agent, segment) tasks over all lanes, 0 = one lane per agent
+  int32_t obs_tasks;  // flat K2, laser-point pass: 1 = (agent, segment) tasks over all lanes, 0 = one lane per agent
+  int32_t obs_lds;    // flat K2: 1 = every wave keeps a copy of the laser points in LDS (set per launch by sfw_launch_social:
+                      // launches that leave the GPU under-filled)
 };
 
 // Shared-prefix rollout (K2).  Under the acceleration limits the robot's first P steps are

@@ -490,7 +490,8 @@ template <typename R> struct sfm_consts {
 struct agent_consts {
   double f_desired, inv_tau, dt, rr, inv_O, l2_f_obstacle, l2e_inv_sigma;
   double f_gaze, f_coherence, f_repulsion;
-  int O, robot_id;
+  const double *obstacles;  // (read with the rest: a lone wave waits for every scalar load it issues on its own)
+  int O, robot_id, obs_tasks;
 };
 __device__ __forceinline__ agent_consts load_agent_consts(late_launch La, bool f32) {
   agent_consts c;
@@ -505,6 +506,8 @@ __device__ __forceinline__ agent_consts load_agent_consts(late_launch La, bool f
   c.f_coherence = La->p.sfm_force_factor_group_coherence;
   c.f_repulsion = La->p.sfm_force_factor_group_repulsion;
   c.O = La->O;
+  c.obstacles = La->obstacles;
+  c.obs_tasks = La->k.obs_tasks;
   c.robot_id = La->agent_c[0].id;
   return c;
 }
@@ -558,7 +561,7 @@ __device__ __forceinline__ void pair_force(const sfm_consts<R> &k, R dx, R dy, R
   // connecting line — which PERSISTS over the steps for a robot driving straight at a person on its axis): the angular
   // term is then exactly 0, as lightsfm's is for theta == 0.  The zero enters through the exponent of the term's 2^k
   // scaling (a compare and ONE select on an integer; as a select on the f64 result it was a compare and two).
-  exp2_fast2_gated(k.pc, fma(k.c_vel, t2, a), fma(k.c_ang, t2, a), __builtin_amdgcn_ballot_w64(cw != 0.0), ev, ea);
+  exp2_fast2_gated(k.pc, fma(k.c_vel, t2, a), fma(k.c_ang, t2, a), cw, ev, ea);
 #endif
   if constexpr (NORM_ONLY) {
     const R q = fma(ev, ev, ea * ea);
@@ -670,8 +673,10 @@ __device__ __forceinline__ void obstacle_segment(const sfm_consts<R> &k, ObsPtr 
 // load, the lanes of a wave walk 16 different segments — and meets the lane's NJ agents.  With one agent per lane the
 // vector memory pipe, not the VALU, set the pace of a 720-point scan (one 16-byte load per 28 issue slots and lane).
 // Every (agent, segment) sum is formed in point order as in obstacle_segment: bit-identical.
-template <typename R, int NJ>
-__device__ __forceinline__ void obstacle_segment_multi(const sfm_consts<R> &k, const double2 *obs, int o_begin, int o_end,
+typedef const __attribute__((address_space(3))) double *obs_lds_ptr;
+__device__ __forceinline__ double2 obs_point(obs_lds_ptr obs, int o) { return double2{obs[2 * o], obs[2 * o + 1]}; }
+template <typename R, int NJ, typename ObsPtr>
+__device__ __forceinline__ void obstacle_segment_multi(const sfm_consts<R> &k, ObsPtr obs, int o_begin, int o_end,
                                                        const double *px, const double *py, R neg_l2e_inv_sigma, R *ax, R *ay) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) ax[j] = ay[j] = R(0);
@@ -685,12 +690,12 @@ __device__ __forceinline__ void obstacle_segment_multi(const sfm_consts<R> &k, c
   // segment, so no lane reads past its points; a clamped (repeated) point is loaded and never evaluated.
   const int last = o_end - 1;
   if (o_begin < o_end) {
-    double2 qa = obs[o_begin];
+    double2 qa = obs_point(obs, o_begin);
 #pragma unroll 1
     for (int o = o_begin; o < o_end; o += 2) {
-      const double2 qb = obs[min(o + 1, last)];
+      const double2 qb = obs_point(obs, min(o + 1, last));
       terms(qa);
-      qa = obs[min(o + 2, last)];
+      qa = obs_point(obs, min(o + 2, last));
       if (o + 1 < o_end) terms(qb);
     }
   }
@@ -808,6 +813,9 @@ __device__ __forceinline__ void obstacle_sums(const sfm_consts<R> &k, const agen
 struct lds_layout {
   double *px, *py, *vx, *vy, *fjx, *fjy, *fcx, *fcy;
   double2 *gcen;
+  double2 *obs;         // flat form, launches that leave the GPU under-filled (sfw_launch.k.obs_lds): the wave's copy of the laser
+                        // points.  A lone wave per SIMD waits out every load it issues, and LDS answers in a quarter of the time
+                        // of the vector L1; in a GPU-filling launch the copy (16 B per point and wave) would cost occupancy instead
   sfw_robot_step *rsb;  // robot records: one per sample of the wave (register form), two (flat form: this step's
                         // and the prefetched next step's)
   sfw_agent_const *ac;  // the per-agent launch constants as they sit in global memory (48 B records: one address
@@ -830,7 +838,7 @@ struct lds_layout {
   // of which the allocator spilled to scratch and reloaded one after the other in every step.
   static constexpr int REG_DEAD_CAP = 32;  // samples per register-form wave (plan_for)
   __host__ __device__ lds_layout(char *base, int A, int cap, int GA, int G, int O, int NG, int NM, bool consts,
-                                 bool with_frc) {
+                                 bool with_frc, bool obs_in_lds = false) {
     char *const base0 = base;
     auto take = [&](size_t n) {
       char *p = base;
@@ -852,6 +860,8 @@ struct lds_layout {
       opart = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? 2 * 64 : 0)));
       wr = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? 4 : 0)));
       oscale = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? A : 0)));
+      obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (obs_in_lds ? O : 0)));
+      if (!obs_in_lds) obs = nullptr;
       hasgoal8 = reinterpret_cast<unsigned char *>(take(static_cast<size_t>(GA)));
       hasgoal = nullptr;
       hg_stride = 1;
@@ -861,6 +871,7 @@ struct lds_layout {
       opart = nullptr;
       wr = nullptr;
       oscale = nullptr;
+      obs = nullptr;
       hasgoal = reinterpret_cast<int *>(take(plane));
       hasgoal8 = nullptr;
       hg_stride = 2;
@@ -1075,6 +1086,8 @@ __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout
       s.ac[i] = L.agent_c[i];
     }
   }
+  if (s.obs)
+    for (int o = lane; o < L.O; o += WAVE) s.obs[o] = double2{L.obstacles[2 * o], L.obstacles[2 * o + 1]};
   if constexpr (GROUPS) {
     for (int i = lane; i < A; i += WAVE) s.grp[i] = L.agent_grp[i];
     for (int q = lane; q <= L.NG; q += WAVE) s.goff[q] = L.grp_off[q];
@@ -1473,7 +1486,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
         if (ok_[r] && lds_at<int>(smem, off::DEAD + g4_[r]) == 0) {
           const uint32_t io = io_[r];
           double tx, ty, sc;
-          obstacle_sums<R, false>(k, c, obs_global(late_args()->obstacles), lds_at<double>(smem, io), lds_at<double>(smem, io + PY),
+          obstacle_sums<R, false>(k, c, obs_global(c.obstacles), lds_at<double>(smem, io), lds_at<double>(smem, io + PY),
                            lds_at<double>(smem, ci_[r] + 32u), tx, ty, sc);
           if (i_[r] == 0) {
             sw[r] += lds_at<double>(smem, io + off::SW) + fast_norm(tx * sc, ty * sc);
@@ -1598,9 +1611,14 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
             FCY = 56 * cap;  // byte offsets from px[] (immediates when CAP > 0)
   (void)FCX;
   (void)FCY;
-  const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, GROUPS, true);
+  const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, GROUPS, true, L.k.obs_lds != 0);
   const int64_t first_local = xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd));
   const sfm_consts<R> k0 = make_consts<R, true>(L);  // the prologue's; every step builds its own (below)
+  // the five force constants stay in scalar registers for the rollout (a step's copy into VGPRs is five v_mov; read from the
+  // kernel arguments every step, a lone wave waited for the scalar loads at the top of each)
+  const sfw_force_k<R> &fk = force_k<R>(L);
+  const R s_lambda = sfwm::sgpr_const(fk.lambda), s_nig = sfwm::sgpr_const(fk.neg_l2e_inv_gamma), s_lfs = sfwm::sgpr_const(fk.l2_f_social),
+          s_cvel = sfwm::sgpr_const(fk.c_vel), s_cang = sfwm::sgpr_const(fk.c_ang);
   constexpr bool F32 = sizeof(R) == 4;
   const int step_begin = L.step_begin, step_end = L.step_end;
   if (!stage_wave<GROUPS, GROUPS>(L, s, lane, 1, 1, first_local)) {
@@ -1761,7 +1779,13 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     // The pair term's constants pinned to VGPRs (five force constants, two leading polynomial coefficients: 14 registers)
     // are (re)built per step: they are opaque to the compiler, so held across the rollout they also sit through the
     // laser-point pass, whose four-agents-per-lane loop needs the registers.
-    const sfm_consts<R> k = make_consts<R, true>(late_args());
+    sfm_consts<R> k = k0;  // the scalar part (15 polynomial coefficients) as built in front of the rollout ...
+    k.pc.leading_here();   // ... the vector part afresh: two leading coefficients and the five force constants
+    k.lambda = sfwm::vgpr_copy_here(s_lambda);
+    k.neg_l2e_inv_gamma = sfwm::vgpr_copy_here(s_nig);
+    k.l2_f_social = sfwm::vgpr_copy_here(s_lfs);
+    k.c_vel = sfwm::vgpr_copy_here(s_cvel);
+    k.c_ang = sfwm::vgpr_copy_here(s_cang);
     if (n_it > 0) {
       uint32_t ia, ja, ib, jb;
       load_pair_entries(tab_i, tab_j, lane_off, ia, ja);
@@ -1839,7 +1863,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     if (with_obs) {
       // Obstacle term: the robot at its pre-step position (Wr's obstacle part), a person at its new position.
       __syncthreads();
-      if (La->k.obs_tasks) {
+      if (c.obs_tasks) {
         // Every (agent, segment) pair is a task; the wave walks them 256 at a time, 16 agents x 16 segments per round (same
         // sums in the same order as obstacle_sums).  Lane l: segment l / 4 of the agents a0 + l % 4 + {0, 4, 8, 12} — four
         // neighbouring lanes read the same point — the points through per-lane loads from global memory (L1), one load per
@@ -1847,28 +1871,40 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
         const int Lseg = (c.O + OBS_SEG - 1) / OBS_SEG, seg = lane >> 2, sub = lane & (OBS_AGENT_LANES - 1);
         const int ob = min(seg * Lseg, c.O), oe = min(ob + Lseg, c.O);
         const R nis = sfwm::vgpr_const(static_cast<R>(-c.l2e_inv_sigma));
-        const double2 *const pts = reinterpret_cast<const double2 *>(La->obstacles);
+        // The wave's LDS copy in an under-filled launch, else global memory — as two instantiations of the loop, not one
+        // over a generic pointer: a flat load counts on vmcnt too, and waiting for it a lone wave also waited, in front of
+        // its first point of every step, for the robot record of the next step that was fetched to be in flight until then.
+        const double2 *const pts_g = reinterpret_cast<const double2 *>(c.obstacles);
+        const obs_lds_ptr pts_l = (obs_lds_ptr)s.obs;
+        const bool in_lds = s.obs != nullptr;
         const double *const part = reinterpret_cast<const double *>(s.opart);
         constexpr int KA = OBS_AGENTS_PER_LANE;
         for (int a0 = 0; a0 < A; a0 += OBS_AGENT_LANES * KA) {
-          // lane (seg, sub) takes agents a0 + sub + 4 j, j < nj (wave-uniform; a lane past the last agent works on zeros)
+          // lane (seg, sub) takes agents a0 + sub + 4 j, j < nj (wave-uniform)
           const int nj = min(KA, (A - a0 + OBS_AGENT_LANES - 1) / OBS_AGENT_LANES);
           double pxj[KA], pyj[KA];
           R axj[KA + 1], ayj[KA + 1];  // (+1: the reduction below takes the slots in twos)
 #pragma unroll
           for (int j = 0; j < KA; ++j) {
-            const int a = a0 + sub + OBS_AGENT_LANES * j;
-            pxj[j] = a < A ? s.px[a] : 0.0;
-            pyj[j] = a < A ? s.py[a] : 0.0;
+            pxj[j] = pyj[j] = 0.0;
+            if (j < nj) {  // (wave-uniform; a lane past the last agent evaluates the last agent's position, unused)
+              const int a = min(a0 + sub + OBS_AGENT_LANES * j, A - 1);
+              pxj[j] = s.px[a];
+              pyj[j] = s.py[a];
+            }
           }
 #pragma unroll
           for (int j = 0; j <= KA; ++j) axj[j] = ayj[j] = R(0);
-          switch (nj) {
-            case 1: obstacle_segment_multi<R, 1>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
-            case 2: obstacle_segment_multi<R, 2>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
-            case (KA > 3 ? 3 : -1): obstacle_segment_multi<R, 3>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
-            default: obstacle_segment_multi<R, KA>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
-          }
+          auto run = [&](auto pts) {
+            switch (nj) {
+              case 1: obstacle_segment_multi<R, 1>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
+              case 2: obstacle_segment_multi<R, 2>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
+              case (KA > 3 ? 3 : -1): obstacle_segment_multi<R, 3>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
+              default: obstacle_segment_multi<R, KA>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
+            }
+          };
+          if (in_lds) run(pts_l);
+          else run(pts_g);
           // The sixteen segment sums of an agent are added in segment order by one lane per component: two of the lanes'
           // agent slots at a time go through LDS (2 KB: what the wave can spare without losing a wave per SIMD at the target
           // crowd), lane l < 16 sums component l & 1 of agent slot j0 + (l >> 1 & 1) of lane group l >> 2.
@@ -1901,7 +1937,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
         for (int a = lane; a < A; a += WAVE) {
           const double rad = GROUPS ? s.ac[a].radius : agent_c[a].radius;
           double tx, ty, sc;
-          obstacle_sums<R, true>(k, c, obs_global(La->obstacles), s.px[a], s.py[a], rad, tx, ty, sc);
+          obstacle_sums<R, true>(k, c, obs_global(c.obstacles), s.px[a], s.py[a], rad, tx, ty, sc);
           if (a == 0) {
             s.swp[0] += s.wr[0] + fast_norm(tx * sc, ty * sc);
           } else {
@@ -2147,19 +2183,28 @@ void sfw_derive(sfw_launch &L) {
 static int flat_cap(int A) { return A < 64 ? 64 : A < 104 ? 104 : A < 128 ? 128 : A < 208 ? 208 : A < 256 ? 256 : 0; }
 static int flat_cap_runtime(int A) { return (A + 2) & ~1; }
 
-static size_t lds_bytes_for(const wave_plan &pl, int A, int O, int NG, int n_grp_mem) {
+// Flat form: does a launch of `items` waves keep its own LDS copy of the laser points?  Yes while it leaves the GPU
+// under-filled (at most two waves per SIMD: LDS is plentiful and every load's latency is exposed) and the scan is at most
+// 32 KB; a GPU-filling launch reads the points through the L1 instead (the copy would cost it occupancy).
+static bool obs_in_lds(const wave_plan &pl, int O, int64_t items, int cus) {
+  return pl.flat && O > 0 && O <= 2048 && items <= static_cast<int64_t>(8) * cus;
+}
+static size_t lds_bytes_for(const wave_plan &pl, int A, int O, int NG, int n_grp_mem, bool obs_lds) {
   if (pl.flat) {
     const int c = flat_cap(A);
-    return lds_layout(nullptr, A, c > 0 ? c : flat_cap_runtime(A), A, 1, O, NG, n_grp_mem, NG > 0, true).bytes;
+    return lds_layout(nullptr, A, c > 0 ? c : flat_cap_runtime(A), A, 1, O, NG, n_grp_mem, NG > 0, true, obs_lds).bytes;
   }
+  (void)obs_lds;
   return lds_layout(nullptr, A, WAVE * pl.ns, pl.G * A, pl.G, O, NG, n_grp_mem, true, false).bytes;
 }
 
 // Largest LDS allocation any launch of a chunk of T samples may ask for (the prefix phase of the
 // shared-prefix rollout may pick the flat organisation where the chunk itself uses the other).
 size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T, int form, int cus) {
-  const size_t a = lds_bytes_for(plan_for(A, T, O, form, cus), A, O, NG, n_grp_mem);
-  const size_t b = (A >= 2 || O > 0) ? lds_bytes_for(wave_plan{1, 0, true}, A, O, NG, n_grp_mem) : 0;
+  const wave_plan pl = plan_for(A, T, O, form, cus);
+  const size_t a = lds_bytes_for(pl, A, O, NG, n_grp_mem, obs_in_lds(pl, O, T, cus));
+  // (a prefix level may hold any number of classes up to T: the flat form with the points' copy is the largest it can ask for)
+  const size_t b = (A >= 2 || O > 0) ? lds_bytes_for(wave_plan{1, 0, true}, A, O, NG, n_grp_mem, O > 0 && O <= 2048) : 0;
   return a > b ? a : b;
 }
 
@@ -2234,14 +2279,17 @@ template <int CAP> static bool reg_layout_matches() {
          at(s.hasgoal) == off::HG && at(s.swp) == off::SW && at(s.dead) == off::DEAD && at(s.rsb) == off::RSB && s.hg_stride == 2;
 }
 
-template <typename R> static hipError_t launch_social_typed(const sfw_launch &L, hipStream_t stream) {
+template <typename R> static hipError_t launch_social_typed(const sfw_launch &L_in, hipStream_t stream) {
   // The organisations are bit-identical and the class records of the shared-prefix rollout are
   // organisation-neutral, so every launch picks its own by its item count (measured: forcing the
   // flat form on an under-filled prefix phase at cfg2 — 2024 register-form waves — changes nothing).
-  const int64_t items = L.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L.n_cls) : L.chunk_count;
-  const wave_plan pl = plan_for(L.A, items, L.O, L.k2_form, L.n_cu > 0 ? L.n_cu : SFW_DEFAULT_CUS);
+  const int64_t items = L_in.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L_in.n_cls) : L_in.chunk_count;
+  const int cus = L_in.n_cu > 0 ? L_in.n_cu : SFW_DEFAULT_CUS;
+  const wave_plan pl = plan_for(L_in.A, items, L_in.O, L_in.k2_form, cus);
   const unsigned grid = static_cast<unsigned>((items + pl.G - 1) / pl.G);
-  const size_t lds = lds_bytes_for(pl, L.A, L.O, L.NG, L.n_grp_mem);
+  sfw_launch L = L_in;
+  L.k.obs_lds = obs_in_lds(pl, L.O, items, cus) ? 1 : 0;
+  const size_t lds = lds_bytes_for(pl, L.A, L.O, L.NG, L.n_grp_mem, L.k.obs_lds != 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static const bool layout_ok = reg_layout_matches<WAVE>() && reg_layout_matches<2 * WAVE>();
   if (!layout_ok) return hipErrorInvalidValue;

@@ -71,6 +71,20 @@ __device__ __forceinline__ double sgpr_const(double c) {
   return c;
 }
 // The opposite pin: keep a wave-uniform value in a VGPR (see make_consts).
+__device__ __forceinline__ float sgpr_const(float c) {
+  asm("" : "+s"(c));
+  return c;
+}
+// from an SGPR into a VGPR, HERE (volatile: not hoisted out of the loop it stands in): a wave-uniform value that lives in
+// scalar registers across a rollout and in vector registers only where a pass needs it there
+__device__ __forceinline__ double vgpr_copy_here(double c) {
+  asm volatile("" : "+v"(c));
+  return c;
+}
+__device__ __forceinline__ float vgpr_copy_here(float c) {
+  asm volatile("" : "+v"(c));
+  return c;
+}
 __device__ __forceinline__ double vgpr_const(double c) {
   asm("" : "+v"(c));
   return c;
@@ -97,9 +111,15 @@ struct poly_consts {
   __device__ __forceinline__ poly_consts() {
 #pragma unroll
     for (int n = 0; n < SFW_ASIN_DEG; ++n) as[n] = sgpr_const(kAsinQ[n]);
-    as[SFW_ASIN_DEG] = vgpr_literal_here<f64_lo(kAsinQ[SFW_ASIN_DEG]), f64_hi(kAsinQ[SFW_ASIN_DEG])>();
 #pragma unroll
     for (int n = 0; n < SFW_EXP_DEG; ++n) ex[n] = sgpr_const(kExp2P[n]);
+    leading_here();
+  }
+  // The two leading coefficients, in VGPRs, materialised where this is called: a kernel that keeps the scalar part across
+  // its rollout (built once: rebuilding it per step is ~70 s_mov, which a lone wave pays in full) calls this once per step,
+  // so that the four vector registers are free during the passes that do not evaluate a polynomial.
+  __device__ __forceinline__ void leading_here() {
+    as[SFW_ASIN_DEG] = vgpr_literal_here<f64_lo(kAsinQ[SFW_ASIN_DEG]), f64_hi(kAsinQ[SFW_ASIN_DEG])>();
     ex[SFW_EXP_DEG] = vgpr_literal_here<f64_lo(kExp2P[SFW_EXP_DEG]), f64_hi(kExp2P[SFW_EXP_DEG])>();
   }
 };
@@ -157,19 +177,19 @@ __device__ __forceinline__ void exp2_fast2(const poly_consts &pc, double x1, dou
   e1 = __builtin_amdgcn_ldexp(p1, __double2loint(t1));
   e2 = __builtin_amdgcn_ldexp(p2, __double2loint(t2));
 }
-// The same with the second exponential exactly 0 in the lanes whose bit of `on2` (a wave64 lane mask in an SGPR pair:
-// __builtin_amdgcn_ballot_w64) is clear: the integer exponent of its 2^k scaling is replaced by one far below the denormals
+// The same with the second exponential exactly 0 in the lanes whose `cw` is zero: the integer exponent of its 2^k scaling is replaced by one far below the denormals
 // (v_ldexp_f64 then returns +0) — one v_cndmask_b32 on the integer instead of two on the result.  The replacement is the bit
 // pattern of -4.0f read as an integer (-1 065 353 216): an INLINE constant of the instruction, so it costs neither a VGPR
 // (the register form sits exactly at its 80-VGPR budget) nor the constant bus (a literal next to the vcc mask does not
-// assemble on gfx9); the asm keeps the compiler from materialising it in a register across the rollout all the same.
-__device__ __forceinline__ int gate_exponent(int k, unsigned long long on) {
+// assemble on gfx9); the asm keeps the compiler from materialising it in a register across the rollout all the same, and
+// the compare writes vcc for the select right behind it (through an SGPR pair and s_mov the two sat on the dependency chain
+// of a lone wave: a control cycle's pair loop ran 8-12 % longer).
+__device__ __forceinline__ int gate_exponent(int k, double cw) {
   int r;
-  asm("s_mov_b64 vcc, %2\n\tv_cndmask_b32_e32 %0, -4.0, %1, vcc" : "=v"(r) : "v"(k), "s"(on) : "vcc");
+  asm("v_cmp_neq_f64 vcc, 0, %2\n\tv_cndmask_b32_e32 %0, -4.0, %1, vcc" : "=v"(r) : "v"(k), "v"(cw) : "vcc");
   return r;
 }
-__device__ __forceinline__ void exp2_fast2_gated(const poly_consts &pc, double x1, double x2, unsigned long long on2, double &e1,
-                                                 double &e2) {
+__device__ __forceinline__ void exp2_fast2_gated(const poly_consts &pc, double x1, double x2, double cw, double &e1, double &e2) {
   const double shift = 6755399441055744.0;  // 1.5 * 2^52
   const double t1 = x1 + shift, t2 = x2 + shift;
   const double k1 = t1 - shift, k2 = t2 - shift;
@@ -181,7 +201,7 @@ __device__ __forceinline__ void exp2_fast2_gated(const poly_consts &pc, double x
     p2 = fma(p2, r2, pc.ex[n]);
   }
   e1 = __builtin_amdgcn_ldexp(p1, __double2loint(t1));
-  e2 = __builtin_amdgcn_ldexp(p2, gate_exponent(__double2loint(t2), on2));
+  e2 = __builtin_amdgcn_ldexp(p2, gate_exponent(__double2loint(t2), cw));
 }
 // theta = |atan2(y, x)| in [0, pi] for y >= 0, from y, nx = -x and rh = 1 / sqrt(x*x + y*y) (the caller has the
 // reciprocal norm already) — without a division and without a select:
@@ -222,11 +242,10 @@ __device__ __forceinline__ void exp2_fast2(const poly_consts &pc, float x1, floa
   e1 = exp2_fast(pc, x1);
   e2 = exp2_fast(pc, x2);
 }
-__device__ __forceinline__ void exp2_fast2_gated(const poly_consts &pc, float x1, float x2, unsigned long long on2, float &e1,
-                                                 float &e2) {
+__device__ __forceinline__ void exp2_fast2_gated(const poly_consts &pc, float x1, float x2, double cw, float &e1, float &e2) {
   e1 = exp2_fast(pc, x1);
   const float e = exp2_fast(pc, x2);
-  asm("s_mov_b64 vcc, %2\n\tv_cndmask_b32_e32 %0, 0, %1, vcc" : "=v"(e2) : "v"(e), "s"(on2) : "vcc");
+  asm("v_cmp_neq_f64 vcc, 0, %2\n\tv_cndmask_b32_e32 %0, 0, %1, vcc" : "=v"(e2) : "v"(e), "v"(cw) : "vcc");
 }
 __device__ __forceinline__ float angle_abs(const poly_consts &, float y, float nx, float /*rh*/, float hyp) {
   const float x = -nx;
