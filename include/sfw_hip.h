@@ -62,6 +62,13 @@ typedef enum sfw_status {
 #define SFW_PRECISION_F32 1 /* fast mode: agent state, integration and every
                                threshold stay double; only the pair/obstacle
                                FORCES are evaluated in float  */
+#define SFW_PRECISION_F64_STRICT 2 /* everything in double as SFW_PRECISION_F64,
+                               with the polynomials of the pair term one degree
+                               longer each (asin 8 / exp 9: that term at ~1e-14
+                               relative instead of ~1e-12; K2 +2.5 %).  For the
+                               caller who wants the last digits of the parity
+                               margin back (what the two buy on
+                               the 3000-scene sweeps)                         */
 
 /*
  * Scoring parameters = the subset of ControllerParams

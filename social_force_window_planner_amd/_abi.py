@@ -17,6 +17,7 @@ SFW_COST_SKIPPED = -2.0
 
 SFW_PRECISION_F64 = 0
 SFW_PRECISION_F32 = 1
+SFW_PRECISION_F64_STRICT = 2
 
 SFW_K2_AUTO, SFW_K2_REGISTER, SFW_K2_FLAT = -1, 0, 1
 SFW_ORG_NONE, SFW_ORG_REGISTER_1, SFW_ORG_REGISTER_2, SFW_ORG_FLAT = 0, 1, 2, 3

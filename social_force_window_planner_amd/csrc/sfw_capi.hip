@@ -215,6 +215,11 @@ int hip_fail(sfw_handle h, hipError_t e, const char *what) {
     if (e_ != hipSuccess) return hip_fail((h), e_, #call); \
   } while (0)
 
+// K2 through the kernels the precision mode names (SFW_PRECISION_F64_STRICT: the build with the longer polynomials)
+hipError_t launch_social_of(const sfw_launch &L, hipStream_t stream) {
+  return L.p.precision == SFW_PRECISION_F64_STRICT ? sfw_launch_social_strict(L, stream) : sfw_launch_social(L, stream);
+}
+
 // SFW_DEVICE_CUS in the environment: pretend a device of that many compute units (planning heuristics only)
 int env_device_cus(int fallback) {
   if (const char *b = std::getenv("SFW_DEVICE_CUS")) {
@@ -242,7 +247,7 @@ int check_params(sfw_handle h, const sfw_params *p) {
   if (!p) return fail(h, SFW_ERR_INVALID_ARG, "params is NULL");
   if (!(p->sim_granularity > 0) || !(p->sim_time >= 0))
     return fail(h, SFW_ERR_INVALID_ARG, "sim_time/sim_granularity out of range");
-  if (p->precision != SFW_PRECISION_F64 && p->precision != SFW_PRECISION_F32)
+  if (p->precision != SFW_PRECISION_F64 && p->precision != SFW_PRECISION_F32 && p->precision != SFW_PRECISION_F64_STRICT)
     return fail(h, SFW_ERR_INVALID_ARG, "unknown precision");
   if (!(p->sfm_gamma > 0) || !(p->sfm_relaxation_time > 0) || !(p->sfm_force_sigma_obstacle > 0))
     return fail(h, SFW_ERR_INVALID_ARG, "sfm gamma/relaxation_time/sigma must be > 0");
@@ -890,7 +895,7 @@ int launch_common(sfw_handle h) {
         }
         L.out_state = h->cls_state[l & 1].p;
         L.out_dead = h->cls_dead[l & 1].p;
-        SFW_HIP(h, sfw_launch_social(L, h->stream));
+        SFW_HIP(h, launch_social_of(L, h->stream));
       }
       SFW_HIP(h, hipStreamWaitEvent(h->stream, h->ev_side, 0));
       L.phase = SFW_PHASE_SUFFIX;
@@ -902,12 +907,12 @@ int launch_common(sfw_handle h) {
       L.col_src = tab + h->prefix_o_col_cls;
       L.in_state = h->cls_state[(n_lv - 1) & 1].p;
       L.in_dead = h->cls_dead[(n_lv - 1) & 1].p;
-      SFW_HIP(h, sfw_launch_social(L, h->stream));
+      SFW_HIP(h, launch_social_of(L, h->stream));
     } else {
       if (!poses_done) SFW_HIP(h, sfw_launch_rollout_poses(L, h->stream));
       SFW_HIP(h, sfw_launch_rollout_costmap(L, h->stream));
       if (timing) SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
-      SFW_HIP(h, sfw_launch_social(L, h->stream));
+      SFW_HIP(h, launch_social_of(L, h->stream));
     }
     if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c + 2], h->stream));
   }
@@ -1280,7 +1285,7 @@ int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp, doubl
   // reference's Trajectory there (ref :613-627 returns before the later illegal pose is ever reached)
   L.force_alive = want_pts ? 1 : 0;
   SFW_HIP(h, sfw_launch_rollout(L, h->stream));
-  SFW_HIP(h, sfw_launch_social(L, h->stream));
+  SFW_HIP(h, launch_social_of(L, h->stream));
   const size_t fetch = head + ((points_xyth && points_cap > 0) ? pts_bytes : 0);
   SFW_HIP(h, h->pin_out.reserve(fetch));
   SFW_HIP(h, hipMemcpyAsync(h->pin_out.p, h->one_out.p, fetch, hipMemcpyDeviceToHost, h->stream));
@@ -1501,7 +1506,7 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
     L.rstep = h->pts_rstep.p;
     L.force_alive = 1;
     SFW_HIP(h, hipMemsetAsync(h->pts_coll.p, 0xff, sizeof(int32_t) * n, h->stream));  // -1: no contact
-    SFW_HIP(h, sfw_launch_social(L, h->stream));
+    SFW_HIP(h, launch_social_of(L, h->stream));
     SFW_HIP(h, hipMemcpyAsync(coll.data(), h->pts_coll.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
     SFW_HIP(h, hipStreamSynchronize(h->stream));
   }

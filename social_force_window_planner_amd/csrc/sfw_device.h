@@ -179,6 +179,10 @@ hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream);  // = po
 hipError_t sfw_launch_rollout_poses(const sfw_launch &L, hipStream_t stream);
 hipError_t sfw_launch_rollout_costmap(const sfw_launch &L, hipStream_t stream);
 hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream);
+#ifndef SFW_STRICT_BUILD
+// the same launcher over the K2 kernels compiled with the longer polynomials (sfw_kernels_strict.hip): SFW_PRECISION_F64_STRICT
+hipError_t sfw_launch_social_strict(const sfw_launch &L, hipStream_t stream);
+#endif
 // true when sfw_launch_rollout_poses runs all of K1 in one launch (small grids): the only form that writes L.points
 bool sfw_rollout_is_fused(const sfw_launch &L);
 // Reduces costs[0..T) to one sfw_sel at *out (device memory).  partials must

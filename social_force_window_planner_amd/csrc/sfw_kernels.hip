@@ -2329,7 +2329,9 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L_
 
 hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream) {
   if (L.chunk_count <= 0 || L.A <= 0) return hipSuccess;
+#ifndef SFW_STRICT_BUILD  // (the strict build of this file holds the f64 kernels only)
   if (L.p.precision == SFW_PRECISION_F32) return launch_social_typed<float>(L, stream);
+#endif
   return launch_social_typed<double>(L, stream);
 }
 

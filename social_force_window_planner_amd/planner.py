@@ -42,7 +42,7 @@ class SfwError(RuntimeError):
 def build(force=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles on CPU)."""
     csrc = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("sfw_capi.hip", "sfw_kernels.hip", "sfw_device.h", "sfw_math.h")]
+    srcs = [os.path.join(csrc, f) for f in ("sfw_capi.hip", "sfw_kernels.hip", "sfw_kernels_strict.hip", "sfw_device.h", "sfw_math.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "sfw_hip.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs)

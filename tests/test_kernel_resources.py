@@ -17,13 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "social_force_window_planner_amd", "csrc")
 
 
-@pytest.fixture(scope="module")
-def resources():
+@pytest.fixture(scope="module", params=["sfw_kernels.hip", "sfw_kernels_strict.hip"])
+def resources(request):
+    """... of both builds of the K2 kernels: the default one and the one with the longer polynomials (SFW_PRECISION_F64_STRICT)"""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only",
-                        "-Rpass-analysis=kernel-resource-usage", "-c", "sfw_kernels.hip", "-o", os.devnull],
+                        "-Rpass-analysis=kernel-resource-usage", "-c", request.param, "-o", os.devnull],
                        cwd=CSRC, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out, cur = {}, None

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from social_force_window_planner_amd import synthetic as syn
-from social_force_window_planner_amd._abi import SFW_PRECISION_F32, default_params
+from social_force_window_planner_amd._abi import SFW_PRECISION_F32, SFW_PRECISION_F64_STRICT, default_params
 
 pytestmark = pytest.mark.gpu
 
@@ -499,3 +499,42 @@ def test_single_sample_and_single_step(oracle_mod, hip_mod):
     assert w.n_steps == 1
     _, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w, n_threads=1)
     _assert_parity(oc, ob, gc, gb, RTOL_F64)
+
+
+# ---------------------------------------------------------------------------
+# SFW_PRECISION_F64_STRICT: the K2 kernels compiled with the polynomial degrees of round 2 (asin 8 / exp 9)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw", [
+    ("cfg2", dict(nv=64, nw=64)),
+    ("cfg2", dict(nv=96, nw=96)),                      # register form + shared prefix
+    ("target", dict(nv=48, nw=48)),
+    ("cfg2", dict(nv=40, nw=40, n_obstacles=240, seed=13)),
+    ("cfg5", dict(nv=12, nw=12)),
+    ("ref5x9", {}),
+])
+def test_f64_strict_mode(oracle_mod, hip_mod, name, kw):
+    """the parity margin round 3 spent on the polynomial degrees is a caller's choice.  The strict mode meets
+    the oracle like the default mode (1e-9 asserted, identical sentinels and selection) and closer (its pair term is at
+    ~1e-14 where the default's is at ~1e-12); both organisations are bit-identical in it too."""
+    from social_force_window_planner_amd._abi import SFW_K2_FLAT, SFW_K2_REGISTER
+
+    w = dataclasses.replace(syn.WORKLOADS[name], **kw)
+    scene, oc, ob, gc, gb = _run_both(oracle_mod, hip_mod, w, n_threads=os.cpu_count(), precision=SFW_PRECISION_F64_STRICT)
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
+    v = oc >= 0
+    err_strict = float(np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])))
+    g = hip_mod.HipScorer(_params_for(w))
+    g.load_scene(scene)
+    dc, db = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    err_default = float(np.max(np.abs(dc[v] - oc[v]) / np.abs(oc[v])))
+    print(f"{name} {kw}: max rel err strict {err_strict:.2e}, default {err_default:.2e}")
+    assert err_strict <= 2e-13 and err_strict <= max(err_default, 5e-14)
+    assert db["index"] == gb["index"] and not np.array_equal(dc, gc)  # other kernels, same answer
+    if w.n_people + 1 <= 128:
+        res = []
+        for form in (SFW_K2_REGISTER, SFW_K2_FLAT):
+            g2 = hip_mod.HipScorer(_params_for(w, precision=SFW_PRECISION_F64_STRICT))
+            g2.set_k2_form(form)
+            g2.load_scene(scene)
+            res.append(g2.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args))
+        assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and np.array_equal(res[0][0], gc)

@@ -8,7 +8,8 @@ python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_gpu_tests.log 2>&1; echo
 bash tools/profile.sh ${TAG}_target target > gpurun_out/${TAG}_prof_target.log 2>&1
 bash tools/profile.sh ${TAG}_cfg2 cfg2 > gpurun_out/${TAG}_prof_cfg2.log 2>&1
 bash tools/profile.sh ${TAG}_cfg2_o64 cfg2_o64 > gpurun_out/${TAG}_prof_cfg2_o64.log 2>&1
-python tools/traffic_json.py target=gpurun_out/${TAG}_target_traffic.txt cfg2=gpurun_out/${TAG}_cfg2_traffic.txt cfg2_o64=gpurun_out/${TAG}_cfg2_o64_traffic.txt > gpurun_out/${TAG}_traffic.json
+bash tools/profile.sh ${TAG}_target_o720 target_o720 > gpurun_out/${TAG}_prof_target_o720.log 2>&1
+python tools/traffic_json.py target=gpurun_out/${TAG}_target_traffic.txt cfg2=gpurun_out/${TAG}_cfg2_traffic.txt cfg2_o64=gpurun_out/${TAG}_cfg2_o64_traffic.txt target_o720=gpurun_out/${TAG}_target_o720_traffic.txt > gpurun_out/${TAG}_traffic.json
 python -c "
 import json; d=json.load(open('gpurun_out/${TAG}_traffic.json'))
 for k,v in d.items(): print(k, 'K2 MB %.1f' % (v['k2_bytes']/1e6), 'all MB %.1f' % (v['all_kernels_bytes']/1e6))"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Large randomized parity sweep (the generator of tests/test_random_scenes_gpu.py with many more
-seeds): HIP f64 and f32 against the CPU oracle.  usage: sweep_parity.py <first_seed> <n_seeds>"""
+seeds): HIP f64 and f32 against the CPU oracle.  usage: sweep_parity.py <first_seed> <n_seeds> [strict]   (strict: SFW_PRECISION_F64_STRICT instead of the default f64 mode)"""
 import os
 import sys
 import time
@@ -12,11 +12,12 @@ import numpy as np
 import test_random_scenes_gpu as gen
 from oracle import sfw_oracle as oracle_mod
 from social_force_window_planner_amd import planner as hip_mod
-from social_force_window_planner_amd._abi import SFW_PRECISION_F32
+from social_force_window_planner_amd._abi import SFW_PRECISION_F32, SFW_PRECISION_F64_STRICT
 
 
 def main():
     first, n = int(sys.argv[1]), int(sys.argv[2])
+    strict = len(sys.argv) > 3 and sys.argv[3] == "strict"
     worst64 = worst32 = worst64_well = worst_default = 0.0
     n_samples = n_valid = bad_status = bad_sel = bad_sel32 = chaotic = unexplained = 0
     t0 = time.time()
@@ -25,6 +26,8 @@ def main():
         o = oracle_mod.OracleScorer(p)
         o.load_scene(scene)
         oc, ob = o.score_grid(rs, lin, ang, ga, n_threads=32)
+        if strict:
+            p.precision = SFW_PRECISION_F64_STRICT
         g = hip_mod.HipScorer(p)
         g.load_scene(scene)
         gc, gb = g.score_grid(rs, lin, ang, ga)
@@ -67,7 +70,7 @@ def main():
         if fb["index"] != ob["index"]:
             bad_sel32 += 1
     print(f"scenes with the lightsfm default parameters (2 of 3): f64 max rel err {worst_default:.3e}")
-    print(f"seeds {first}..{first + n - 1}: {n_samples} samples ({n_valid} valid), f64 max rel err {worst64_well:.3e} over the "
+    print(f"{'SFW_PRECISION_F64_STRICT' if strict else 'SFW_PRECISION_F64'}, seeds {first}..{first + n - 1}: {n_samples} samples ({n_valid} valid), f64 max rel err {worst64_well:.3e} over the "
           f"well-conditioned scenes, {chaotic} chaotic scenes (error within {gen.CHAOS_FACTOR:.0f} x the oracle's own response to 2e-14 input noise, worst "
           f"{worst64:.3e}), {unexplained} unexplained, "
           f"status mismatches {bad_status}, selection mismatches {bad_sel}; f32 mode max rel err {worst32:.3e}, "
