@@ -686,16 +686,16 @@ __device__ __forceinline__ void obstacle_segment_multi(const sfm_consts<R> &k, O
     for (int j = 0; j < NJ; ++j) obstacle_term<R>(k, q, px[j], py[j], nis, ax[j], ay[j]);
   };
   // One point ahead, two register sets in turn: the load of the next point is in flight while a point meets the lane's
-  // agents (a lone wave — a control cycle's — otherwise sits out an L1 round trip per point).  The index is clamped to the
-  // segment, so no lane reads past its points; a clamped (repeated) point is loaded and never evaluated.
-  const int last = o_end - 1;
+  // agents (a lone wave — a control cycle's — otherwise sits out a round trip per point).  The loads run up to two points
+  // past the segment — into the next segment, or into the padding behind the last point (64 bytes in global memory,
+  // sfw_set_agents; two points in the LDS copy, lds_layout): loaded, never evaluated, and no index to clamp.
   if (o_begin < o_end) {
     double2 qa = obs_point(obs, o_begin);
 #pragma unroll 1
     for (int o = o_begin; o < o_end; o += 2) {
-      const double2 qb = obs_point(obs, min(o + 1, last));
+      const double2 qb = obs_point(obs, o + 1);
       terms(qa);
-      qa = obs_point(obs, min(o + 2, last));
+      qa = obs_point(obs, o + 2);
       if (o + 1 < o_end) terms(qb);
     }
   }
@@ -860,7 +860,7 @@ struct lds_layout {
       opart = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? 2 * 64 : 0)));
       wr = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? 4 : 0)));
       oscale = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? A : 0)));
-      obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (obs_in_lds ? O : 0)));
+      obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (obs_in_lds ? O + 2 : 0)));  // + 2: read ahead, never evaluated
       if (!obs_in_lds) obs = nullptr;
       hasgoal8 = reinterpret_cast<unsigned char *>(take(static_cast<size_t>(GA)));
       hasgoal = nullptr;
@@ -1087,7 +1087,7 @@ __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout
     }
   }
   if (s.obs)
-    for (int o = lane; o < L.O; o += WAVE) s.obs[o] = double2{L.obstacles[2 * o], L.obstacles[2 * o + 1]};
+    for (int o = lane; o < L.O + 2; o += WAVE) s.obs[o] = o < L.O ? double2{L.obstacles[2 * o], L.obstacles[2 * o + 1]} : double2{0.0, 0.0};
   if constexpr (GROUPS) {
     for (int i = lane; i < A; i += WAVE) s.grp[i] = L.agent_grp[i];
     for (int q = lane; q <= L.NG; q += WAVE) s.goff[q] = L.grp_off[q];
@@ -2184,10 +2184,13 @@ static int flat_cap(int A) { return A < 64 ? 64 : A < 104 ? 104 : A < 128 ? 128 
 static int flat_cap_runtime(int A) { return (A + 2) & ~1; }
 
 // Flat form: does a launch of `items` waves keep its own LDS copy of the laser points?  Yes while it leaves the GPU
-// under-filled (at most two waves per SIMD: LDS is plentiful and every load's latency is exposed) and the scan is at most
-// 32 KB; a GPU-filling launch reads the points through the L1 instead (the copy would cost it occupancy).
-static bool obs_in_lds(const wave_plan &pl, int O, int64_t items, int cus) {
-  return pl.flat && O > 0 && O <= 2048 && items <= static_cast<int64_t>(8) * cus;
+// under-filled (at most two waves per SIMD: LDS is plentiful and every load's latency is exposed); a GPU-filling launch
+// reads the points through the L1 instead (the copy would cost it occupancy).
+static size_t lds_bytes_for(const wave_plan &pl, int A, int O, int NG, int n_grp_mem, bool obs_lds);
+// (... and only while the wave's whole allocation stays within 64 KB: the copy is an optimisation and must never be what
+// makes an agent set exceed the LDS of a compute unit)
+static bool obs_in_lds(const wave_plan &pl, int A, int O, int NG, int n_grp_mem, int64_t items, int cus) {
+  return pl.flat && O > 0 && items <= static_cast<int64_t>(8) * cus && lds_bytes_for(pl, A, O, NG, n_grp_mem, true) <= 64 * 1024;
 }
 static size_t lds_bytes_for(const wave_plan &pl, int A, int O, int NG, int n_grp_mem, bool obs_lds) {
   if (pl.flat) {
@@ -2202,9 +2205,11 @@ static size_t lds_bytes_for(const wave_plan &pl, int A, int O, int NG, int n_grp
 // shared-prefix rollout may pick the flat organisation where the chunk itself uses the other).
 size_t sfw_social_lds_bytes(int A, int O, int NG, int n_grp_mem, int64_t T, int form, int cus) {
   const wave_plan pl = plan_for(A, T, O, form, cus);
-  const size_t a = lds_bytes_for(pl, A, O, NG, n_grp_mem, obs_in_lds(pl, O, T, cus));
-  // (a prefix level may hold any number of classes up to T: the flat form with the points' copy is the largest it can ask for)
-  const size_t b = (A >= 2 || O > 0) ? lds_bytes_for(wave_plan{1, 0, true}, A, O, NG, n_grp_mem, O > 0 && O <= 2048) : 0;
+  const size_t a = lds_bytes_for(pl, A, O, NG, n_grp_mem, obs_in_lds(pl, A, O, NG, n_grp_mem, T, cus));
+  // (a prefix level may hold any number of classes up to T: the flat form — with the points' copy where that is allowed — is
+  // the largest it can ask for)
+  const wave_plan fl{1, 0, true};
+  const size_t b = (A >= 2 || O > 0) ? lds_bytes_for(fl, A, O, NG, n_grp_mem, obs_in_lds(fl, A, O, NG, n_grp_mem, 1, cus)) : 0;
   return a > b ? a : b;
 }
 
@@ -2288,7 +2293,7 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L_
   const wave_plan pl = plan_for(L_in.A, items, L_in.O, L_in.k2_form, cus);
   const unsigned grid = static_cast<unsigned>((items + pl.G - 1) / pl.G);
   sfw_launch L = L_in;
-  L.k.obs_lds = obs_in_lds(pl, L.O, items, cus) ? 1 : 0;
+  L.k.obs_lds = obs_in_lds(pl, L.A, L.O, L.NG, L.n_grp_mem, items, cus) ? 1 : 0;
   const size_t lds = lds_bytes_for(pl, L.A, L.O, L.NG, L.n_grp_mem, L.k.obs_lds != 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static const bool layout_ok = reg_layout_matches<WAVE>() && reg_layout_matches<2 * WAVE>();

@@ -132,9 +132,9 @@ def test_laser_points(oracle_mod, hip_mod, n_people, n_obs, grouped, seed, form,
 
 
 # (e) a GPU-filling grid (> 4096 samples): the organisation the automatic plan picks, through the shared-prefix tree
-@pytest.mark.parametrize("kind", ["groups", "rest", "o64", "plain51"])
+@pytest.mark.parametrize("kind", ["groups", "rest", "o64", "plain51", "o720_51"])
 def test_gpu_filling_grid_automatic_plan(oracle_mod, hip_mod, kind):
-    nv, nw = (72, 64) if kind == "plain51" else (96, 96)  # enough register-form waves (three samples each) for sharing to pay
+    nv, nw = (72, 64) if kind in ("plain51", "o720_51") else (96, 96)  # enough register-form waves (three samples each) for sharing to pay
     rs = None
     if kind == "groups":
         scene = _grouped_scene(20, 71, nv=nv, nw=nw)
@@ -142,6 +142,9 @@ def test_gpu_filling_grid_automatic_plan(oracle_mod, hip_mod, kind):
         scene, rs = _rest_scene(20, 504, True, nv=nv, nw=nw)
     elif kind == "o64":
         scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["cfg2_o64"], nv=nv, nw=nw))
+    elif kind == "o720_51":  # the north-star crowd with a whole scan on a GPU-filling grid: the flat form's task loop reading
+        # the points from global memory (small grids keep an LDS copy: test_laser_points), against the oracle and the register form
+        scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["target_o720"], nv=nv, nw=nw))
     else:
         scene = syn.make_scene(dataclasses.replace(syn.WORKLOADS["cfg2"], nv=nv, nw=nw, n_people=50, seed=752))
     rs = scene.robot_state if rs is None else rs
@@ -152,7 +155,7 @@ def test_gpu_filling_grid_automatic_plan(oracle_mod, hip_mod, kind):
     info = g.plan_info()
     assert info["levels"] > 0, "no shared-prefix tree on a GPU-filling grid"
     # 21 agents: three samples per register-form wave; 51 agents (the north-star crowd): the flat form wins (80 % of the lanes otherwise)
-    assert info["organisation"] == (SFW_ORG_FLAT if kind == "plain51" else SFW_ORG_REGISTER_1)
+    assert info["organisation"] == (SFW_ORG_FLAT if kind in ("plain51", "o720_51") else SFW_ORG_REGISTER_1)
     g.launch()
     gc, gb, _ = g.fetch()
     o = oracle_mod.OracleScorer(p)
