@@ -2122,7 +2122,7 @@ static wave_plan plan_for(int A, int64_t T, int O, int form, int cus) {
     const double c_reg = (A <= WAVE) ? (90.0 * rows + 225.0) / reg.G : 0.9 * (180.0 * rows + 450.0);
     if (c_reg < c_flat) best = reg;
   }
-  // ... and a robot alone among laser points: the flat form spreads the points over eight lanes
+  // ... and a robot alone among laser points: the flat form spreads the points' sixteen segments over sixteen lanes
   // (the item thresholds were measured on 256 compute units and scale with the device: 6 / 12 / 16 items per CU)
   if (T <= static_cast<int64_t>(A <= 8 ? 6 : A <= 12 ? 12 : 16) * cus && (A >= 2 || O > 0)) best = flat;
   if (form == SFW_K2_FLAT && (A >= 2 || O > 0)) best = flat;

@@ -114,7 +114,9 @@ def test_relative_rest(oracle_mod, hip_mod, n_people, robot_moving, form, prec, 
 
 
 # (d) laser points: O = 64 at A = 21 (BASELINE-adjacent `cfg2_o64`), O = 7 with groups, O = 1, O = 240 with two slots, a whole
-#     720-point scan (scalar-cache loads in the wave-uniform loops, the LDS copy in the eight-lanes pass)
+#     720-point scan (scalar-cache loads in the wave-uniform loops; on these small grids the flat form's (agent, segment)
+#     task loop reads the wave's LDS copy of the points, on a GPU-filling grid — test_gpu_filling_grid_automatic_plan[o720_51] —
+#     global memory; the lane-per-agent pass with hand-pipelined scalar loads where the scan is short: (99, 33), (59, 7))
 @pytest.mark.parametrize("prec,rtol", PRECISIONS)
 @pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("n_people,n_obs,grouped,seed", [(20, 64, False, 0), (20, 7, True, 60), (59, 7, True, 99), (20, 1, False, 0),
