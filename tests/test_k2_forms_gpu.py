@@ -12,6 +12,7 @@ Reference being matched: sfm::SFM.computeForces / updatePosition (group, obstacl
 /root/reference/src/sfw_planner.cpp:592-594, computeSocialWork :678-705, group ids src/sensor_interface.cpp:448-449.
 """
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -203,3 +204,42 @@ def test_forms_are_bit_identical_and_the_knob_validates(hip_mod):
     g.load_scene(scene)
     g.stage(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
     assert g.plan_info()["organisation"] == SFW_ORG_FLAT
+
+
+# (g) random crowd x scan sizes: the laser-point pass picks its form per launch (tasks over all lanes or one lane per agent,
+#     LDS copy or global loads) from A, O and the item count — whatever it picks, both organisations agree bit for bit and
+#     meet the oracle; small grids (lone waves) and a GPU-filling one
+@pytest.mark.parametrize("seed", range(12))
+def test_laser_points_random_sizes(oracle_mod, hip_mod, seed):
+    rng = np.random.default_rng(4400 + seed)
+    n_people = int(rng.choice([0, 1, 3, 4, 5, 11, 15, 16, 17, 31, 47, 48, 63, 64, 80, 127]))
+    n_obs = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 100, 129, 255, 400, 721]))
+    big = seed % 4 == 3
+    nv, nw = (48, 64) if big else (int(rng.integers(1, 6)), int(rng.integers(2, 8)))
+    if big:
+        n_people = min(n_people, 31)  # (keeps the oracle's share of the test short)
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=nv, nw=nw, n_people=n_people, seed=4500 + seed, n_obstacles=n_obs,
+                            sim_time=float(rng.choice([0.25, 0.5, 1.0])))
+    scene = syn.make_scene(w)
+    # a scan with structure: the ring of make_scene, every other point pulled in or pushed out
+    scene.obstacles[::2] *= rng.uniform(0.5, 1.5)
+    kw = dict(sim_time=w.sim_time, sim_granularity=w.sim_granularity)
+    res = []
+    for form in (SFW_K2_REGISTER, SFW_K2_FLAT):
+        if n_people == 0 and form == SFW_K2_REGISTER:
+            continue
+        g = hip_mod.HipScorer(default_params(**kw))
+        g.set_k2_form(form)
+        g.load_scene(scene)
+        res.append(g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args))
+    for c, b in res[1:]:
+        assert np.array_equal(c, res[0][0]) and b == res[0][1], (n_people, n_obs, nv, nw)
+    o = oracle_mod.OracleScorer(default_params(**kw))
+    o.load_scene(scene)
+    rows = np.unique(np.linspace(0, nv - 1, min(nv, 3)).round().astype(int))
+    oc, _ = o.score_grid(scene.robot_state, scene.linvels[rows], scene.angvels, scene.goal_args, n_threads=os.cpu_count())
+    gc = res[0][0].reshape(nv, nw)[rows].ravel()
+    assert np.array_equal(oc < 0, gc < 0) and np.array_equal(oc[oc < 0], gc[gc < 0])
+    v = oc >= 0
+    if v.any():
+        assert np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64, (n_people, n_obs)
