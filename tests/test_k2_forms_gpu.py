@@ -225,9 +225,7 @@ def test_laser_points_random_sizes(oracle_mod, hip_mod, seed):
     scene.obstacles[::2] *= rng.uniform(0.5, 1.5)
     kw = dict(sim_time=w.sim_time, sim_granularity=w.sim_granularity)
     res = []
-    for form in (SFW_K2_REGISTER, SFW_K2_FLAT):
-        if n_people == 0 and form == SFW_K2_REGISTER:
-            continue
+    for form in (SFW_K2_REGISTER, SFW_K2_FLAT):  # (a robot alone among the points too: 32 samples per register-form wave)
         g = hip_mod.HipScorer(default_params(**kw))
         g.set_k2_form(form)
         g.load_scene(scene)
