@@ -1615,7 +1615,7 @@ __device__ __forceinline__ void wait_pair_entries(uint32_t &io, uint32_t &jo) {
 #ifndef SFW_FLAT_WAVES
 #define SFW_FLAT_WAVES 5  // waves per SIMD the flat kernel is compiled for (<= 96 VGPRs; tuning knob, csrc/Makefile EXTRA)
 #endif
-template <typename R, bool GROUPS, int CAP>
+template <typename R, bool GROUPS, int CAP, bool OBS>
 __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVES) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   (void)G_unused;
@@ -1679,7 +1679,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       double fx = 0.0, fy = 0.0;
       if (sl != 0) {
         desired_force(c0, px, py, vx, vy, c.has_goal != 0, c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity, fx, fy);
-        if (O > 0) {
+        if (OBS && O > 0) {
           double tx, ty, sc;
           obstacle_sums<R, true>(k0, c0, obs_global(L.obstacles), px, py, c.radius, tx, ty, sc);
           fx = fma(tx, sc, fx);
@@ -1695,7 +1695,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
       s.fjx[sl] = s.fjy[sl] = 0.0;
     }
   }
-  if (O > 0) {
+  if (OBS && O > 0) {
     const agent_consts c0 = load_agent_consts(late_args(), F32);
     for (int sl = lane; sl < A; sl += WAVE) s.oscale[sl] = obstacle_scale<R>(k0, c0, L.agent_c[sl].radius);
   }
@@ -1791,17 +1791,22 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
 #endif
   };
 
+  // The kernel exists twice: with and without the laser-point pass (OBS).  With it, the pair term's constants pinned to VGPRs
+  // (five force constants, two leading polynomial coefficients: 14 registers) are refreshed per step — they are opaque to the
+  // compiler, so held across the rollout they also sit through that pass, whose four-agents-per-lane loop needs the
+  // registers.  Without it they are built once: the refresh is ~30 vector instructions per step (the v_mov and the reloads of
+  // the scalar constants it pushes out), 1.5 % of a step at the target crowd and 5 % of a lone wave's step with 5 people.
+  // (Two kernels, not two loops in one: with both in one function the backend fails — "illegal VGPR to SGPR copy".)
   for (int step = step_begin; step < step_end; ++step) {
-    // The pair term's constants pinned to VGPRs (five force constants, two leading polynomial coefficients: 14 registers)
-    // are (re)built per step: they are opaque to the compiler, so held across the rollout they also sit through the
-    // laser-point pass, whose four-agents-per-lane loop needs the registers.
     sfm_consts<R> k = k0;  // the scalar part (15 polynomial coefficients) as built in front of the rollout ...
-    k.pc.leading_here();   // ... the vector part afresh: two leading coefficients and the five force constants
-    k.lambda = sfwm::vgpr_copy_here(s_lambda);
-    k.neg_l2e_inv_gamma = sfwm::vgpr_copy_here(s_nig);
-    k.l2_f_social = sfwm::vgpr_copy_here(s_lfs);
-    k.c_vel = sfwm::vgpr_copy_here(s_cvel);
-    k.c_ang = sfwm::vgpr_copy_here(s_cang);
+    if constexpr (OBS) {
+      k.pc.leading_here();   // ... the vector part afresh: two leading coefficients and the five force constants
+      k.lambda = sfwm::vgpr_copy_here(s_lambda);
+      k.neg_l2e_inv_gamma = sfwm::vgpr_copy_here(s_nig);
+      k.l2_f_social = sfwm::vgpr_copy_here(s_lfs);
+      k.c_vel = sfwm::vgpr_copy_here(s_cvel);
+      k.c_ang = sfwm::vgpr_copy_here(s_cang);
+    }
     if (n_it > 0) {
       uint32_t ia, ja, ib, jb;
       load_pair_entries(tab_i, tab_j, lane_off, ia, ja);
@@ -1834,7 +1839,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVE
     // (fetched ONE step ahead.  Two steps ahead into a third slot — so that no barrier of a step finds the fetch still in
     // flight — was measured on the control cycle and is slower: +3 % without laser points, +5 % with them, 32 bytes of scratch)
     if (step + 1 < step_end) fetch_robot(La->rstep, La->rstep_stride, step + 1, (step + 1) & 1);
-    const bool with_obs = c.O > 0;
+    const bool with_obs = OBS && c.O > 0;  // (the GROUPS kernels exist with OBS only and serve both cases)
     // the lane index, opaque once per step: the 64-bit byte offset of the lane's agent constants (48 * lane) is then formed
     // here (two instructions) instead of being held — in scratch, for the 104- and 208-double capacities — across the pair loop
     int lane_s = lane;
@@ -2321,25 +2326,32 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L_
   if (!pl.flat && pl.G > lds_layout::REG_DEAD_CAP) return hipErrorInvalidValue;
   if (pl.flat) {
     if (8 * (static_cast<int64_t>(L.A) + 1) > 65535 || !L.pair_tab) return hipErrorInvalidValue;  // 16-bit plane offsets
+    const bool obs = L.O > 0;  // the kernels with the laser-point pass (sfw_social_kernel_flat<.., OBS>)
     switch (flat_cap(L.A)) {
       case 64:
-        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 64>, L, 1, grid, lds, stream)
-                      : launch_social_as(sfw_social_kernel_flat<R, false, 64>, L, 1, grid, lds, stream);
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 64, true>, L, 1, grid, lds, stream)
+               : obs  ? launch_social_as(sfw_social_kernel_flat<R, false, 64, true>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 64, false>, L, 1, grid, lds, stream);
       case 104:
-        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 104>, L, 1, grid, lds, stream)
-                      : launch_social_as(sfw_social_kernel_flat<R, false, 104>, L, 1, grid, lds, stream);
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 104, true>, L, 1, grid, lds, stream)
+               : obs  ? launch_social_as(sfw_social_kernel_flat<R, false, 104, true>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 104, false>, L, 1, grid, lds, stream);
       case 128:
-        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 128>, L, 1, grid, lds, stream)
-                      : launch_social_as(sfw_social_kernel_flat<R, false, 128>, L, 1, grid, lds, stream);
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 128, true>, L, 1, grid, lds, stream)
+               : obs  ? launch_social_as(sfw_social_kernel_flat<R, false, 128, true>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 128, false>, L, 1, grid, lds, stream);
       case 208:
-        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 208>, L, 1, grid, lds, stream)
-                      : launch_social_as(sfw_social_kernel_flat<R, false, 208>, L, 1, grid, lds, stream);
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 208, true>, L, 1, grid, lds, stream)
+               : obs  ? launch_social_as(sfw_social_kernel_flat<R, false, 208, true>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 208, false>, L, 1, grid, lds, stream);
       case 256:
-        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 256>, L, 1, grid, lds, stream)
-                      : launch_social_as(sfw_social_kernel_flat<R, false, 256>, L, 1, grid, lds, stream);
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 256, true>, L, 1, grid, lds, stream)
+               : obs  ? launch_social_as(sfw_social_kernel_flat<R, false, 256, true>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 256, false>, L, 1, grid, lds, stream);
       default:
-        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 0>, L, 1, grid, lds, stream)
-                      : launch_social_as(sfw_social_kernel_flat<R, false, 0>, L, 1, grid, lds, stream);
+        return groups ? launch_social_as(sfw_social_kernel_flat<R, true, 0, true>, L, 1, grid, lds, stream)
+               : obs  ? launch_social_as(sfw_social_kernel_flat<R, false, 0, true>, L, 1, grid, lds, stream)
+                      : launch_social_as(sfw_social_kernel_flat<R, false, 0, false>, L, 1, grid, lds, stream);
     }
   }
   if (groups) {

@@ -53,6 +53,8 @@ def test_register_form_six_waves_without_scratch(resources):
 
 
 def test_flat_form_five_waves_without_scratch(resources):
+    """... both kernels of every plane capacity: without the laser-point pass (the headline's) and with it"""
     for cap in (64, 104, 128, 208, 256):
-        k = _kernel(resources, f"sfw_social_kernel_flatIdLb0ELi{cap}E")
-        assert k["vgpr"] <= 96 and k["scratch"] == 0 and k["occupancy"] >= 5, (cap, k)
+        for obs in (0, 1):
+            k = _kernel(resources, f"sfw_social_kernel_flatIdLb0ELi{cap}ELb{obs}E")
+            assert k["vgpr"] <= 96 and k["scratch"] == 0 and k["occupancy"] >= 5, (cap, obs, k)

@@ -4,7 +4,7 @@
 OUT=${OUT:-/tmp/k2_isa.s}
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function --cuda-device-only -S "$@" \
   social_force_window_planner_amd/csrc/sfw_kernels.hip -o $OUT 2>&1 | grep -v "hip-link" 
-for sym in sfw_social_kernel_flatIdLb0ELi64E sfw_social_kernelIdLi1ELb0E; do
+for sym in sfw_social_kernel_flatIdLb0ELi64ELb0E sfw_social_kernel_flatIdLb0ELi64ELb1E sfw_social_kernelIdLi1ELb0E; do
   echo "== $sym"
   python tools/isa_loops.py $OUT $sym | awk '{ if ($6+0 >= 60) print }'
   awk -v s="$sym" '$0 ~ "^\t.set .*"s".*(num_vgpr|numbered_sgpr|private_seg_size)," {print "   " $2, $3}' $OUT
