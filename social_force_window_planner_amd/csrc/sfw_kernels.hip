@@ -1615,8 +1615,11 @@ __device__ __forceinline__ void wait_pair_entries(uint32_t &io, uint32_t &jo) {
 #ifndef SFW_FLAT_WAVES
 #define SFW_FLAT_WAVES 5  // waves per SIMD the flat kernel is compiled for (<= 96 VGPRs; tuning knob, csrc/Makefile EXTRA)
 #endif
+#ifndef SFW_FLAT_WAVES_NOOBS
+#define SFW_FLAT_WAVES_NOOBS 6  // ... the kernel without the laser-point pass (77 VGPRs: six waves per SIMD)
+#endif
 template <typename R, bool GROUPS, int CAP, bool OBS>
-__global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : SFW_FLAT_WAVES) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
+__global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLAT_WAVES : SFW_FLAT_WAVES_NOOBS) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   (void)G_unused;
   const int lane = threadIdx.x;
