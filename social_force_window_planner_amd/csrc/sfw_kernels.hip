@@ -645,6 +645,14 @@ __device__ __forceinline__ obs_global_ptr obs_global(const double *obstacles) {
 }
 __device__ __forceinline__ double2 obs_point(const double2 *obs, int o) { return obs[o]; }
 __device__ __forceinline__ double2 obs_point(obs_global_ptr obs, int o) { return double2{obs[2 * o], obs[2 * o + 1]}; }
+// The hand-pipelined scalar loads of obstacle_sums (obs_group_issue / _wait: the next four points' s_load in flight while four
+// are evaluated, across the segment boundaries) — what VERDICT r3 asked for — measured and OFF: their scalar bookkeeping per
+// group of four costs more than the latency they hide, with several waves per SIMD (register form, cfg2 + 240 points: K2 3.33
+// -> 3.56 ms) and for a lone wave alike (flat form's lane-per-agent pass, control cycle with 50 people and 60 points: K2 474
+// -> 499 us, 16 points: 385 -> 409).  -DSFW_FLAT_PIPELINED=true builds them into the flat form's lane-per-agent pass.
+#ifndef SFW_FLAT_PIPELINED
+#define SFW_FLAT_PIPELINED false
+#endif
 #ifndef SFW_OBS_UNROLL_SCALAR
 #define SFW_OBS_UNROLL_SCALAR 4  // points per s_load group of a wave-uniform loop (4: one s_load_dwordx16)
 #endif
@@ -740,9 +748,8 @@ __device__ __forceinline__ void obs_group_wait(obs_group &g) { asm volatile("s_w
 // organisations stopped being bit-identical the day it chose differently.
 // The points array is readable 48 bytes past its last point (sfw_set_agents pads it): the last group of a segment is
 // loaded whole and evaluated up to the segment's end.
-// PIPELINED = false: the compiler's loop (s_load, wait, four terms).  The register form, which only runs with several
-// waves per SIMD, uses it: there the other waves cover the load and the hand-pipelined loop's extra scalar bookkeeping
-// costs 5-7 % (cfg2 + 240 points K2 3.33 -> 3.56 ms, same-session).  Same sums in the same order either way.
+// PIPELINED = false (every caller's default, see SFW_FLAT_PIPELINED): the compiler's loop (s_load, wait, four interleaved
+// terms).  Same sums in the same order either way.
 template <typename R, bool PIPELINED>
 __device__ __forceinline__ void obstacle_sums(const sfm_consts<R> &k, const agent_consts &c, obs_global_ptr obs, double px,
                                               double py, double radius, double &tx_out, double &ty_out, double &scale) {
@@ -1684,7 +1691,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
         desired_force(c0, px, py, vx, vy, c.has_goal != 0, c.goal_x, c.goal_y, c.goal_radius, c.desired_velocity, fx, fy);
         if (OBS && O > 0) {
           double tx, ty, sc;
-          obstacle_sums<R, true>(k0, c0, obs_global(L.obstacles), px, py, c.radius, tx, ty, sc);
+          obstacle_sums<R, SFW_FLAT_PIPELINED>(k0, c0, obs_global(L.obstacles), px, py, c.radius, tx, ty, sc);
           fx = fma(tx, sc, fx);
           fy = fma(ty, sc, fy);
         }
@@ -1944,26 +1951,34 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
               const int a = a0 + gsub + OBS_AGENT_LANES * (j0 + js);
               if (lane < 16 && a < A) {
                 const double *const col = part + 2 * (WAVE * js + gsub) + comp;  // segment q of that agent: + 2 * 4 * q
+                // all sixteen loads first, then the additions in segment order (left to the compiler: load two, wait, add two,
+                // eight LDS round trips one after the other — 850 cycles of a lone wave's step per phase)
+                double v[OBS_SEG];
+#pragma unroll
+                for (int q = 0; q < OBS_SEG; ++q) v[q] = col[2 * OBS_AGENT_LANES * q];
+                double *const acc = (comp == 0 ? s.fcx : s.fcy) + a;  // (the robot's: not used)
+                const double sc = s.oscale[a], acc0 = *acc, wr0 = s.wr[0];
+                asm volatile("" ::: "memory");
                 R t = R(0);  // + 0 first, as obstacle_sums does; empty segments of a short scan add +0
 #pragma unroll
-                for (int q = 0; q < OBS_SEG; ++q) t += static_cast<R>(col[2 * OBS_AGENT_LANES * q]);
-                const double sc = s.oscale[a];
-                if (a == 0) s.wr[1 + comp] = static_cast<double>(t) * sc;
-                else if (comp == 0) s.fcx[a] = fma(static_cast<double>(t), sc, s.fcx[a]);
-                else s.fcy[a] = fma(static_cast<double>(t), sc, s.fcy[a]);
+                for (int q = 0; q < OBS_SEG; ++q) t += static_cast<R>(v[q]);
+                const double f = static_cast<double>(t) * sc;
+                // the robot's Wr needs both components: lane 1 (y) hands its to lane 0 (x) — a lane swap inside the quad, no LDS
+                const double f_other = __shfl_xor(f, 1, WAVE);
+                if (a != 0) *acc = fma(static_cast<double>(t), sc, acc0);
+                else if (comp == 0) s.swp[0] += wr0 + fast_norm(f, f_other);
               }
               __syncthreads();
             }
           }
         }
-        if (lane == 0) s.swp[0] += s.wr[0] + fast_norm(s.wr[1], s.wr[2]);
       } else {
         // A short scan: the agent's lane runs the sixteen segments itself, the points through the scalar cache (the rounds
         // of the task loop cost more than they spread; sfw_derive prices both)
         for (int a = lane; a < A; a += WAVE) {
           const double rad = GROUPS ? s.ac[a].radius : agent_c[a].radius;
           double tx, ty, sc;
-          obstacle_sums<R, true>(k, c, obs_global(c.obstacles), s.px[a], s.py[a], rad, tx, ty, sc);
+          obstacle_sums<R, SFW_FLAT_PIPELINED>(k, c, obs_global(c.obstacles), s.px[a], s.py[a], rad, tx, ty, sc);
           if (a == 0) {
             s.swp[0] += s.wr[0] + fast_norm(tx * sc, ty * sc);
           } else {
