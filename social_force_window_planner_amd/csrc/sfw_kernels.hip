@@ -20,7 +20,10 @@
 //                            the state in LDS.  Social work accumulated per
 //                            lane and reduced per sample (reference :613-629,
 //                            :678-705).  Group forces only in the GROUPS=true
-//                            instantiations.
+//                            instantiations; the flat form exists with and
+//                            without the laser-point pass (OBS); the whole file
+//                            is compiled a second time with longer polynomials
+//                            for SFW_PRECISION_F64_STRICT (sfw_kernels_strict.hip).
 //   K3  sfw_argmin_*         block-wide + grid argmin under the reference's
 //                            selection order (reference :394-414).
 //

@@ -49,7 +49,8 @@ struct ControllerParams {
   float sfm_goal_weight_ = 2.0f, sfm_obstacle_weight_ = 20.0f, sfm_people_weight_ = 12.0f;  // read, never applied
   double social_weight_ = 1.2, costmap_weight_ = 2.0, angle_weight_ = 0.7, distance_weight_ = 1.0,
          vel_weight_ = 1.0;
-  // not in the reference: arithmetic mode of the device kernels
+  // not in the reference: arithmetic mode of the device kernels (SFW_PRECISION_F64, _F64_STRICT — the same with longer
+  // polynomials in the pair term —, or _F32: forces in float; include/sfw_hip.h)
   int precision_ = SFW_PRECISION_F64;
   sfw_params toAbi() const;
 };
