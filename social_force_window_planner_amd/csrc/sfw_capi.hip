@@ -1168,8 +1168,10 @@ int sfw_set_agents(sfw_handle h, const sfw_agent *agents, int32_t A, const doubl
   // host blob (uploaded with the next stage): pos | vel | const | obstacles | grp | off | mem
   auto up16 = [](size_t b) { return (b + 15) & ~size_t(15); };
   const size_t o_pos = 0, o_vel = o_pos + up16(16 * An), o_cst = o_vel + up16(16 * An),
-               o_obs = o_cst + up16(sizeof(sfw_agent_const) * An), o_grp = o_obs + up16(16 * On) + 64,  // + 64: the kernels read the points in groups of four (s_load_dwordx16)
-
+               o_obs = o_cst + up16(sizeof(sfw_agent_const) * An),
+               // + 64 behind the points: the kernels read them in groups of four (s_load_dwordx16) and, in the flat form's task
+               // loop, up to two points ahead of the one being evaluated, without clamping the index (loaded, never used)
+               o_grp = o_obs + up16(16 * On) + 64,
                o_off = o_grp + up16(4 * An), o_mem = o_off + up16(4 * off.size()),
                total = o_mem + up16(4 * mem.size());
   h->h_agents.assign(total, 0);

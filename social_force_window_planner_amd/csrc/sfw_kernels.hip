@@ -622,7 +622,7 @@ __device__ __forceinline__ void desired_force(const agent_consts &k, double px, 
 //   [k exp(radius/sigma) / O] * sum_o 2^(-|p - o| log2(e)/sigma) / |p - o| * (p - o):
 // the agent's constant factor multiplies the finished sum (obstacle_scale), so the exponent inside the loop is a plain
 // product with the distance and is formed inside the two fma of the exponential's range reduction (exp2_scaled).
-// 25 VALU instructions per (agent, point), one of them the four-slot v_rsq_f64: 28 issue slots (round 3: 29).
+// 24 VALU instructions per (agent, point), one of them the four-slot v_rsq_f64: 27 issue slots (round 3: 29).
 //
 // Summation order (the same in both kernel organisations, so that they stay bit-identical): the points are cut
 // into OBS_SEG = 16 consecutive segments of L = ceil(O / 16) points; a segment's terms are added in point order
@@ -682,7 +682,7 @@ __device__ __forceinline__ void obstacle_segment(const sfm_consts<R> &k, ObsPtr 
 }
 // The same segment for NJ agents at once (the flat form's task loop): a point is loaded ONCE per lane — a per-lane vector
 // load, the lanes of a wave walk 16 different segments — and meets the lane's NJ agents.  With one agent per lane the
-// vector memory pipe, not the VALU, set the pace of a 720-point scan (one 16-byte load per 28 issue slots and lane).
+// vector memory pipe, not the VALU, set the pace of a 720-point scan (one 16-byte load per 27 issue slots and lane).
 // Every (agent, segment) sum is formed in point order as in obstacle_segment: bit-identical.
 typedef const __attribute__((address_space(3))) double *obs_lds_ptr;
 __device__ __forceinline__ double2 obs_point(obs_lds_ptr obs, int o) { return double2{obs[2 * o], obs[2 * o + 1]}; }
@@ -733,7 +733,7 @@ __device__ __forceinline__ double obstacle_scale(const sfm_consts<R> &k, const a
   return static_cast<double>(sfwm::exp2_fast(k.pc, static_cast<R>(fma(radius, c.l2e_inv_sigma, c.l2_f_obstacle)))) * c.inv_O;
 }
 // Four points = one s_load_dwordx16 into 16 SGPRs, issued and awaited by hand: the loads of a wave-uniform pass are
-// software-pipelined ACROSS the segments — while a group of four points is evaluated (4 x 28 issue slots) the next group's
+// software-pipelined ACROSS the segments — while a group of four points is evaluated (4 x 27 issue slots) the next group's
 // load is in flight, also when that group opens the next segment.  Left to the compiler every s_load was followed at once
 // by s_waitcnt lgkmcnt(0) (scalar loads return out of order: any use needs the counter at zero), so a lone wave — a control
 // cycle, a coarse shared-prefix level — sat out the scalar-cache latency once per four points, sixteen times per agent and
@@ -1231,6 +1231,7 @@ template <int FX, int FY> __device__ __forceinline__ void lds_add_pair(uint32_t 
 // ---------------------------------------------------------------------------
 template <typename R, int NS, bool GROUPS>
 __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social_kernel(const sfw_launch L, const int G) {
+  sfwm::fp_mode_for_omod();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CAP = WAVE * NS;  // GA <= CAP: state planes at compile-time distances
   using off = reg_off<CAP>;       // byte offsets from a slot's px word
@@ -1630,6 +1631,7 @@ __device__ __forceinline__ void wait_pair_entries(uint32_t &io, uint32_t &jo) {
 #endif
 template <typename R, bool GROUPS, int CAP, bool OBS>
 __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLAT_WAVES : SFW_FLAT_WAVES_NOOBS) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
+  sfwm::fp_mode_for_omod();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   (void)G_unused;
   const int lane = threadIdx.x;
@@ -2209,13 +2211,13 @@ void sfw_derive(sfw_launch &L) {
   L.k.rr = static_cast<double>(static_cast<float>(p.robot_radius) * static_cast<float>(p.robot_radius));  // ref :617
   L.k.inv_O = L.O > 0 ? 1.0 / L.O : 0.0;
   // Flat form, laser-point pass: (agent, segment) tasks over all 64 lanes, or one lane per agent?  Issue slots per step
-  // (28 per evaluation; a round of the task loop also costs its two reduction phases, ~40 slots each):
+  // (27 per evaluation; a round of the task loop also costs its two reduction phases, ~40 slots each):
   {
     const int A = L.A, O = L.O, Lseg = (O + OBS_SEG - 1) / OBS_SEG;
     const int full = A / (OBS_AGENT_LANES * OBS_AGENTS_PER_LANE), rest = (A % (OBS_AGENT_LANES * OBS_AGENTS_PER_LANE) + OBS_AGENT_LANES - 1) / OBS_AGENT_LANES;
     const double red = 40.0;
-    const double c_tasks = full * (28.0 * Lseg * OBS_AGENTS_PER_LANE + 2 * red) + (rest ? 28.0 * Lseg * rest + ((rest + 1) / 2) * red : 0.0);
-    const double c_lane = 28.0 * O * ((A + WAVE - 1) / WAVE);
+    const double c_tasks = full * (27.0 * Lseg * OBS_AGENTS_PER_LANE + 2 * red) + (rest ? 27.0 * Lseg * rest + ((rest + 1) / 2) * red : 0.0);
+    const double c_lane = 27.0 * O * ((A + WAVE - 1) / WAVE);
     L.k.obs_tasks = (O > 0 && c_tasks < c_lane) ? 1 : 0;
   }
 }

@@ -123,13 +123,35 @@ struct poly_consts {
     ex[SFW_EXP_DEG] = vgpr_literal_here<f64_lo(kExp2P[SFW_EXP_DEG]), f64_hi(kExp2P[SFW_EXP_DEG])>();
   }
 };
+// The Newton step of the reciprocal square root needs (1 - x y^2) / 2.  The halving is the VOP3 output modifier of the fma
+// (div:2), which the hardware applies only with FP64 denormals flushed and the IEEE bit of the MODE register off
+// (measured on gfx950, build/omod: ignored otherwise): every kernel that reaches rsqrt_sqrt(double) calls
+// fp_mode_for_omod() first, as its first statement (the fma is an ordinary asm — a volatile one keeps loops with a run-time
+// trip count from being unrolled —: its operands derive from loads, and no load moves across the volatile mode switch; a
+// kernel that forgot the call would be off by 1e-7 in every norm and fail every parity test).  The result is the bit
+// pattern of fma(-x/2, y^2, 1/2) (scaling by two commutes with the rounding); what changes is that results below 2.2e-308
+// (an exponential with an argument under -708) become 0 where they were denormal: no sum of forces can tell.
+#ifndef SFW_OMOD
+#define SFW_OMOD 1
+#endif
+__device__ __forceinline__ void fp_mode_for_omod() {
+#if SFW_OMOD
+  // MODE[7:6] = FP_DENORM of f64 / f16: 0 = flush inputs and outputs; MODE[9] = IEEE
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0");
+#endif
+}
 // v_rsq_f64 / v_rcp_f64 deliver ~23 good bits; one Newton step gives ~46.
 // x must be > 0 and finite (callers clamp with fmax).
 __device__ __forceinline__ void rsqrt_sqrt(double x, double &rs, double &sq) {
   const double y = __builtin_amdgcn_rsq(x);
+#if SFW_OMOD
+  double e;  // (1 - x y^2) / 2 in one issue
+  [[clang::noconvergent]] { asm("v_fma_f64 %0, -%1, %2, 1.0 div:2" : "=v"(e) : "v"(x), "v"(y * y)); }
+#else
   const double h = 0.5 * x;
   const double e = fma(-h, y * y, 0.5);  // Newton: y1 = y0 (1.5 - 0.5 x y0^2) = y0 + y0 (0.5 - 0.5 x y0^2): the same four
-  rs = fma(y, e, y);                     // issues with 0.5 (an inline constant) instead of 1.5 (a literal in a VGPR pair)
+#endif                                   // issues with 0.5 (an inline constant) instead of 1.5 (a literal in a VGPR pair)
+  rs = fma(y, e, y);
   sq = x * rs;
 }
 __device__ __forceinline__ double rcp_nr(double x) {
