@@ -656,6 +656,9 @@ __device__ __forceinline__ double2 obs_point(obs_global_ptr obs, int o) { return
 #ifndef SFW_FLAT_PIPELINED
 #define SFW_FLAT_PIPELINED false
 #endif
+#ifndef SFW_OBS_UNIFORM
+#define SFW_OBS_UNIFORM 1  // the task loop of a GPU-filling launch with wave-uniform trip counts (obstacle_segment_multi_uniform)
+#endif
 #ifndef SFW_OBS_UNROLL_SCALAR
 #define SFW_OBS_UNROLL_SCALAR 4  // points per s_load group of a wave-uniform loop (4: one s_load_dwordx16)
 #endif
@@ -726,6 +729,59 @@ __device__ __forceinline__ void obstacle_segment_multi(const sfm_consts<R> &k, O
       }
     }
   }
+}
+// The task loop of a GPU-FILLING launch (points in global memory): the same sums with wave-uniform trip counts.  A lane's
+// segment holds Lseg points, or the `partial` rest of the scan, or none: written with the lane's own bounds (above) the loop
+// is divergent — index, compare, address and the copies between the two register sets cost 8 vector instructions per point
+// next to the 4 x 24 of the terms (PMC: 26.6 per evaluation).  Here the wave runs `partial` iterations with every lane that
+// has points and Lseg - partial more with the lanes of the full segments: scalar counter, scalar base address + the lane's
+// fixed byte offset (global_load saddr form), loads written as asm one point ahead into two register sets that the
+// unrolled body alternates without copying — the waits are explicit, the compiler does not count an asm load.  Reads up to
+// two points past the range like the loop above.
+typedef double obs_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ obs_d2 obs_load_ahead(const double2 *base, uint32_t lane_bytes) {
+  obs_d2 q;
+  // (s_nop 4: the base may have just come back from an SGPR spill lane — v_readlane — and a VMEM instruction reading such an
+  // SGPR needs 5 wait states, which the hazard recogniser does not insert into an asm block: load_pair_entries)
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(q) : "v"(lane_bytes), "s"(base) : "memory");
+  return q;
+}
+// the oldest of the point loads has arrived (YOUNGER: point loads issued after it; loads return in order, and whatever
+// else is in flight — the next step's robot record — is older than both)
+template <int YOUNGER> __device__ __forceinline__ void obs_load_wait(obs_d2 &q) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q) : "n"(YOUNGER));
+}
+template <typename R, int NJ>
+__device__ __forceinline__ void obstacle_segment_multi_uniform(const sfm_consts<R> &k, const double2 *obs, int O, int Lseg, int seg,
+                                                               const double *px, const double *py, R neg_l2e_inv_sigma, R *ax,
+                                                               R *ay) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) ax[j] = ay[j] = R(0);
+  const R nis = neg_l2e_inv_sigma;
+  auto terms = [&](const obs_d2 q) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) obstacle_term<R>(k, double2{q.x, q.y}, px[j], py[j], nis, ax[j], ay[j]);
+  };
+  const int n_full = O / Lseg, partial = O - n_full * Lseg;  // wave-uniform: full segments, points of the one behind them
+  const uint32_t lane_bytes = static_cast<uint32_t>(seg * Lseg) * 16u;
+  auto run = [&](const double2 *base, int n) {  // n > 0 points from base[lane's first point] on, every active lane alike
+    obs_d2 qa = obs_load_ahead(base, lane_bytes);
+    int i = 0;
+#pragma unroll 1
+    for (; i + 2 <= n; i += 2) {
+      obs_d2 qb = obs_load_ahead(base + i + 1, lane_bytes);
+      obs_load_wait<1>(qa);
+      terms(qa);
+      qa = obs_load_ahead(base + i + 2, lane_bytes);
+      obs_load_wait<1>(qb);
+      terms(qb);
+    }
+    obs_load_wait<0>(qa);  // (also when it is not evaluated: no load of this loop is left in flight)
+    if (i < n) terms(qa);
+  };
+  const int first = partial > 0 ? partial : Lseg;  // points every non-empty segment has
+  if (seg < n_full + (partial > 0 ? 1 : 0)) run(obs, first);
+  if (first < Lseg && seg < n_full) run(obs + first, Lseg - first);
 }
 // what an agent's sum over the points is multiplied with: k exp(radius / sigma) / O
 template <typename R>
@@ -1941,7 +1997,17 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
               default: obstacle_segment_multi<R, KA>(k, pts, ob, oe, pxj, pyj, nis, axj, ayj); break;
             }
           };
+          // (a GPU-filling launch — points in global memory — runs the loop with wave-uniform trip counts)
+          auto run_uniform = [&]() {
+            switch (nj) {
+              case 1: obstacle_segment_multi_uniform<R, 1>(k, pts_g, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
+              case 2: obstacle_segment_multi_uniform<R, 2>(k, pts_g, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
+              case (KA > 3 ? 3 : -1): obstacle_segment_multi_uniform<R, 3>(k, pts_g, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
+              default: obstacle_segment_multi_uniform<R, KA>(k, pts_g, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
+            }
+          };
           if (in_lds) run(pts_l);
+          else if (SFW_OBS_UNIFORM) run_uniform();
           else run(pts_g);
           // The sixteen segment sums of an agent are added in segment order by one lane per component: two of the lanes'
           // agent slots at a time go through LDS (2 KB: what the wave can spare without losing a wave per SIMD at the target
