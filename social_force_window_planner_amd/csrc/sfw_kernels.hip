@@ -659,6 +659,9 @@ __device__ __forceinline__ double2 obs_point(obs_global_ptr obs, int o) { return
 #ifndef SFW_OBS_UNIFORM
 #define SFW_OBS_UNIFORM 1  // the task loop of a GPU-filling launch with wave-uniform trip counts (obstacle_segment_multi_uniform)
 #endif
+#ifndef SFW_OBS_UNIFORM_LDS
+#define SFW_OBS_UNIFORM_LDS 1  // ... and of an under-filled one (LDS copy of the points)
+#endif
 #ifndef SFW_OBS_UNROLL_SCALAR
 #define SFW_OBS_UNROLL_SCALAR 4  // points per s_load group of a wave-uniform loop (4: one s_load_dwordx16)
 #endif
@@ -750,6 +753,37 @@ __device__ __forceinline__ obs_d2 obs_load_ahead(const double2 *base, uint32_t l
 // else is in flight — the next step's robot record — is older than both)
 template <int YOUNGER> __device__ __forceinline__ void obs_load_wait(obs_d2 &q) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q) : "n"(YOUNGER));
+}
+// (LDS copy of the points — an under-filled launch —: the same two loops with the compiler's own loads)
+template <typename R, int NJ>
+__device__ __forceinline__ void obstacle_segment_multi_uniform(const sfm_consts<R> &k, obs_lds_ptr obs, int O, int Lseg, int seg,
+                                                               const double *px, const double *py, R neg_l2e_inv_sigma, R *ax,
+                                                               R *ay) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) ax[j] = ay[j] = R(0);
+  const R nis = neg_l2e_inv_sigma;
+  auto terms = [&](const double2 q) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) obstacle_term<R>(k, q, px[j], py[j], nis, ax[j], ay[j]);
+  };
+  const int n_full = O / Lseg, partial = O - n_full * Lseg;
+  const obs_lds_ptr mine = obs + 2 * (seg * Lseg);
+  auto run = [&](obs_lds_ptr base, int n) {
+    double2 qa = obs_point(base, 0);
+    int i = 0;
+#pragma unroll 1
+    for (; i + 2 <= n; i += 2) {
+      const double2 qb = obs_point(base, i + 1);
+      const double2 qn = obs_point(base, i + 2);
+      terms(qa);
+      terms(qb);
+      qa = qn;
+    }
+    if (i < n) terms(qa);
+  };
+  const int first = partial > 0 ? partial : Lseg;
+  if (seg < n_full + (partial > 0 ? 1 : 0)) run(mine, first);
+  if (first < Lseg && seg < n_full) run(mine + 2 * first, Lseg - first);
 }
 template <typename R, int NJ>
 __device__ __forceinline__ void obstacle_segment_multi_uniform(const sfm_consts<R> &k, const double2 *obs, int O, int Lseg, int seg,
@@ -1998,16 +2032,18 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
             }
           };
           // (a GPU-filling launch — points in global memory — runs the loop with wave-uniform trip counts)
-          auto run_uniform = [&]() {
+          auto run_uniform = [&](auto pts) {
             switch (nj) {
-              case 1: obstacle_segment_multi_uniform<R, 1>(k, pts_g, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
-              case 2: obstacle_segment_multi_uniform<R, 2>(k, pts_g, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
-              case (KA > 3 ? 3 : -1): obstacle_segment_multi_uniform<R, 3>(k, pts_g, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
-              default: obstacle_segment_multi_uniform<R, KA>(k, pts_g, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
+              case 1: obstacle_segment_multi_uniform<R, 1>(k, pts, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
+              case 2: obstacle_segment_multi_uniform<R, 2>(k, pts, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
+              case (KA > 3 ? 3 : -1): obstacle_segment_multi_uniform<R, 3>(k, pts, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
+              default: obstacle_segment_multi_uniform<R, KA>(k, pts, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
             }
           };
-          if (in_lds) run(pts_l);
-          else if (SFW_OBS_UNIFORM) run_uniform();
+          if (in_lds) {
+            if (SFW_OBS_UNIFORM_LDS) run_uniform(pts_l);
+            else run(pts_l);
+          } else if (SFW_OBS_UNIFORM) run_uniform(pts_g);
           else run(pts_g);
           // The sixteen segment sums of an agent are added in segment order by one lane per component: two of the lanes'
           // agent slots at a time go through LDS (2 KB: what the wave can spare without losing a wave per SIMD at the target
