@@ -241,3 +241,29 @@ def test_laser_points_random_sizes(oracle_mod, hip_mod, seed):
     v = oc >= 0
     if v.any():
         assert np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= RTOL_F64, (n_people, n_obs)
+
+# (h) the flat form's task loop at the sizes where its two wave-uniform loops change shape (obstacle_segment_multi_uniform:
+#     `rest` iterations with every lane that has points, ceil(O/16) - rest more with the lanes of the full segments; empty
+#     segments for O < 16; one to four agents per lane): bit-identical with the register form, whose lanes walk the sixteen
+#     segments with scalar loops — in a GPU-filling launch (points from global memory, hand-placed loads) and in a small one
+#     (LDS copy of the points).  The register form meets the oracle at these sizes in (e) and (g).
+@pytest.mark.parametrize("n_obs", [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 95, 97, 250])
+@pytest.mark.parametrize("filling", [False, True])
+def test_task_loop_edge_sizes(hip_mod, n_obs, filling):
+    nv, nw = (48, 64) if filling else (3, 5)
+    for n_people in (2, 20, 37):  # 1 / 2 + 4 / 2 + 4 + 4 agents per lane in the rounds of the task loop
+        w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=nv, nw=nw, n_people=n_people, seed=4700 + n_obs, n_obstacles=n_obs,
+                                sim_time=0.25)
+        scene = syn.make_scene(w)
+        scene.obstacles[1::3] *= 0.7
+        kw = dict(sim_time=w.sim_time, sim_granularity=w.sim_granularity)
+        res = []
+        for form in (SFW_K2_REGISTER, SFW_K2_FLAT):
+            g = hip_mod.HipScorer(default_params(**kw))
+            g.set_k2_form(form)
+            g.load_scene(scene)
+            res.append(g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args))
+            if form == SFW_K2_FLAT:
+                assert g.plan_info()["organisation"] == SFW_ORG_FLAT
+        assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1], (n_people, n_obs, filling)
+        assert (res[0][0] >= 0).any()
