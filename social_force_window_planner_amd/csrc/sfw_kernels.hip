@@ -690,6 +690,8 @@ __device__ __forceinline__ void obstacle_segment(const sfm_consts<R> &k, ObsPtr 
 // load, the lanes of a wave walk 16 different segments — and meets the lane's NJ agents.  With one agent per lane the
 // vector memory pipe, not the VALU, set the pace of a 720-point scan (one 16-byte load per 27 issue slots and lane).
 // Every (agent, segment) sum is formed in point order as in obstacle_segment: bit-identical.
+// This version walks the lane's own bounds [o_begin, o_end) — a divergent loop; the kernels run obstacle_segment_multi_uniform
+// below (SFW_OBS_UNIFORM / SFW_OBS_UNIFORM_LDS = 0 build this one back in: profiles/r04_ab_uniform*.txt).
 typedef const __attribute__((address_space(3))) double *obs_lds_ptr;
 __device__ __forceinline__ double2 obs_point(obs_lds_ptr obs, int o) { return double2{obs[2 * o], obs[2 * o + 1]}; }
 template <typename R, int NJ, typename ObsPtr>

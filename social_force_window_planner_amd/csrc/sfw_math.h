@@ -125,7 +125,7 @@ struct poly_consts {
 };
 // The Newton step of the reciprocal square root needs (1 - x y^2) / 2.  The halving is the VOP3 output modifier of the fma
 // (div:2), which the hardware applies only with FP64 denormals flushed and the IEEE bit of the MODE register off
-// (measured on gfx950, build/omod: ignored otherwise): every kernel that reaches rsqrt_sqrt(double) calls
+// (measured on gfx950, tools/omod_test.hip: ignored otherwise): every kernel that reaches rsqrt_sqrt(double) calls
 // fp_mode_for_omod() first, as its first statement (the fma is an ordinary asm — a volatile one keeps loops with a run-time
 // trip count from being unrolled —: its operands derive from loads, and no load moves across the volatile mode switch; a
 // kernel that forgot the call would be off by 1e-7 in every norm and fail every parity test).  The result is the bit
