@@ -67,6 +67,10 @@ ControllerParams SFWPlannerNode::readControllerParams() {
   c.angle_weight_ = param(n, p + "angle_weight", 0.7);
   c.distance_weight_ = param(n, p + "distance_weight", 1.0);
   c.vel_weight_ = param(n, p + "velocity_weight", 1.0);
+  // not in the reference: arithmetic mode of the device kernels (include/sfw_hip.h) — "f64" (default), "f64_strict" (the pair
+  // term's polynomials one degree longer), "f32" (forces in float)
+  const std::string precision = param<std::string>(n, p + "device_precision", "f64");
+  c.precision_ = precision == "f32" ? SFW_PRECISION_F32 : precision == "f64_strict" ? SFW_PRECISION_F64_STRICT : SFW_PRECISION_F64;
   return c;
 }
 // Parameter names exactly as reference sensor_interface.hpp:78-124.
