@@ -662,6 +662,9 @@ __device__ __forceinline__ double2 obs_point(obs_global_ptr obs, int o) { return
 #ifndef SFW_OBS_UNIFORM_LDS
 #define SFW_OBS_UNIFORM_LDS 1  // ... and of an under-filled one (LDS copy of the points)
 #endif
+#ifndef SFW_SKIP_EMPTY_K2
+#define SFW_SKIP_EMPTY_K2 1  // a robot alone without laser points: sfw_no_social_kernel instead of K2
+#endif
 #ifndef SFW_OBS_UNROLL_SCALAR
 #define SFW_OBS_UNROLL_SCALAR 4  // points per s_load group of a wave-uniform loop (4: one s_load_dwordx16)
 #endif
@@ -2489,8 +2492,24 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L_
   return launch_social_as(sfw_social_kernel<R, 2, false>, L, pl.G, grid, lds, stream);
 }
 
+// A robot alone without a laser point has no social work to integrate: no pair, no obstacle force, so Wr = |0| and Wp = 0
+// at every step, nobody to run into, and K2 would walk its S dependent steps to add social_weight x 0 to the base cost
+// (65 us of a 118 us control cycle; BASELINE cfg1).  This writes what finish_wave would have written.
+namespace {
+__global__ void __launch_bounds__(256) sfw_no_social_kernel(const sfw_launch L) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= L.chunk_count) return;
+  const int64_t t = L.chunk_begin + i;
+  if (L.status[t] == SFW_ST_VALID) L.costs[t] = L.base_cost[t] + L.p.social_weight * 0.0;
+}
+}  // namespace
+
 hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream) {
   if (L.chunk_count <= 0 || L.A <= 0) return hipSuccess;
+  if (SFW_SKIP_EMPTY_K2 && L.A == 1 && L.O == 0 && L.NG == 0 && L.phase != SFW_PHASE_PREFIX && !L.out_state) {
+    hipLaunchKernelGGL(sfw_no_social_kernel, dim3(static_cast<unsigned>((L.chunk_count + 255) / 256)), dim3(256), 0, stream, L);
+    return hipGetLastError();
+  }
 #ifndef SFW_STRICT_BUILD  // (the strict build of this file holds the f64 kernels only)
   if (L.p.precision == SFW_PRECISION_F32) return launch_social_typed<float>(L, stream);
 #endif
