@@ -104,6 +104,9 @@ WORKLOADS = {
     "target_o720": Workload("target_o720", 256, 256, 50, 500, 1.0, seed=6, n_obstacles=720),
     "cfg3": Workload("cfg3", 256, 256, 50, 500, 2.0, seed=3),
     "cfg4": Workload("cfg4", 1024, 1024, 200, 500, 1.0, seed=4),
+    # ... with SURVEY §8d's crowd as specified (pedestrians from 0.8 m): every sample ends in a pedestrian contact before the
+    # horizon, so a launch times rollouts cut short and selects nothing (tests/test_parity_gpu.py::test_cfg4_spec_crowd_full_size)
+    "cfg4_spec": Workload("cfg4_spec", 1024, 1024, 200, 500, 1.0, seed=4, people_r_in=0.8),
     "cfg5": Workload("cfg5", 4096, 4096, 100, 500, 1.0, seed=5),
     "target": Workload("target", 256, 256, 50, 500, 1.0, seed=6),
     "ref5x9": Workload("ref5x9", 5, 9, 5, 200, 1.0, seed=7, sampler="reference"),
