@@ -58,3 +58,55 @@ def test_flat_form_five_waves_without_scratch(resources):
         for obs in (0, 1):
             k = _kernel(resources, f"sfw_social_kernel_flatIdLb0ELi{cap}ELb{obs}E")
             assert k["vgpr"] <= 96 and k["scratch"] == 0 and k["occupancy"] >= 5, (cap, obs, k)
+
+
+# ---- instruction counts of the hot loops, from the ISA (DESIGN.md §3 quotes them; the path is bound by the FP64 operations it
+# issues, so a compiler or source change that adds one shows here before it shows on a GPU) ----
+@pytest.fixture(scope="module")
+def isa_loops():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, "k2.s")
+        r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only", "-S",
+                            "sfw_kernels.hip", "-o", asm], cwd=CSRC, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+
+        def loops(symbol):
+            out = subprocess.run(["python3", os.path.join(ROOT, "tools", "isa_loops.py"), asm, symbol], capture_output=True, text=True,
+                                 timeout=120)
+            assert out.returncode == 0, out.stderr[-1000:]
+            res = []
+            for line in out.stdout.splitlines():
+                m = re.search(r"valu\s+(\d+) \(f64 (\d+), trans (\d+)\)\s+salu\s+(\d+)\s+ds\s+(\d+)\s+vmem\s+(\d+)", line)
+                if m:
+                    res.append(dict(zip(("valu", "f64", "trans", "salu", "ds", "vmem"), map(int, m.groups()))))
+            return res
+
+        yield {"flat": loops("sfw_social_kernel_flatIdLb0ELi64ELb0E"), "flat_obs": loops("sfw_social_kernel_flatIdLb0ELi64ELb1E"),
+               "reg": loops("sfw_social_kernelIdLi1ELb0E")}
+
+
+def test_pair_loop_instruction_counts(isa_loops):
+    """Flat form: the loop body holds two 64-pair iterations (8 + 8 state reads, 4 + 4 atomics, 4 rsq): <= 85 VALU instructions per
+    pair.  Register form: one partner per iteration, 2 rsq, the partner's state through LDS: <= 90."""
+    flat = [l for l in isa_loops["flat"] if l["trans"] == 4 and l["ds"] == 24]
+    assert len(flat) == 1 and flat[0]["valu"] <= 170, isa_loops["flat"]
+    reg = [l for l in isa_loops["reg"] if l["trans"] == 2 and l["ds"] >= 8 and l["valu"] < 120]
+    assert len(reg) == 1 and reg[0]["valu"] <= 90, isa_loops["reg"]
+
+
+def test_laser_point_loop_instruction_counts(isa_loops):
+    """24 VALU instructions per (agent, point), one of them v_rsq_f64.  The flat form's task loops with wave-uniform trip counts
+    carry no other vector instruction (global-memory loops: 2 points x 1..4 agents per iteration, 2 loads) or three per
+    iteration (LDS copy); the register form's scalar loop: 4 points per s_load_dwordx16."""
+    obs = isa_loops["flat_obs"]
+    for nj in (1, 2, 3, 4):
+        g = [l for l in obs if l["trans"] == 2 * nj and l["vmem"] == 2 and l["ds"] == 0 and l["f64"] == 48 * nj]
+        assert g and all(l["valu"] == 48 * nj for l in g), (nj, obs)
+        lds = [l for l in obs if l["trans"] == 2 * nj and l["vmem"] == 0 and l["ds"] == 2 and l["f64"] == 48 * nj]
+        assert lds and all(l["valu"] <= 48 * nj + 3 for l in lds), (nj, obs)
+    reg = [l for l in isa_loops["reg"] if l["trans"] == 4 and l["ds"] == 0 and l["vmem"] == 0]
+    assert reg and all(l["valu"] == 96 for l in reg), isa_loops["reg"]
