@@ -540,6 +540,8 @@ def extra_entry(name, precision, steps, warmup, ctx):
         "roofline_frac": rf["frac"],
         "roofline_executed_frac": rf["executed_frac"],
         "chunks": j.plan["chunks"],
+        "k2_organisation": j.plan["organisation"],  # SFW_ORG_*: 1 / 2 register-resident slots, 3 flat
+        "flat_samples": j.plan["flat_samples"],  # samples a register-form launch hands to concurrent flat-form waves
         "sustained_clock_ghz": r["clock_ghz"],
         "cmd_vel_index": r["best"]["index"],
         "n_valid": r["best"]["n_valid"],

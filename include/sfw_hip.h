@@ -265,6 +265,9 @@ typedef struct sfw_plan_info {
   int64_t classes;     /* classes of the last level, summed over chunks      */
   int64_t class_steps; /* sum over levels of classes x steps of the level    */
   int64_t samples;     /* nv * nw                                            */
+  int64_t flat_samples; /* organisation = SFW_ORG_REGISTER_1 only: samples (of the first chunk's launch) that the launch
+                           hands to flat-form waves running beside the register-form ones, so that every SIMD holds
+                           the same number of those (0: none).  Costs do not depend on it.                      */
 } sfw_plan_info;
 int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out);
 /* The plan a single-chunk stage of this grid would choose, computed on the

@@ -93,6 +93,8 @@ struct sfw_planner_s {
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;  // K1b + K1c beside the shared-prefix phase of K2
   hipEvent_t ev_poses = nullptr, ev_side = nullptr;
+  // the samples' K2 launch may hand its last items to flat-form waves on `side` (sfw_launch_social, sfw_split_streams)
+  sfw_split_streams split{nullptr, nullptr, nullptr};
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> chunk_ev;  // 3 per chunk of a multi-chunk launch: K1 start, K1 end/K2 start, K2 end
   int n_chunks = 1;
@@ -216,8 +218,8 @@ int hip_fail(sfw_handle h, hipError_t e, const char *what) {
   } while (0)
 
 // K2 through the kernels the precision mode names (SFW_PRECISION_F64_STRICT: the build with the longer polynomials)
-hipError_t launch_social_of(const sfw_launch &L, hipStream_t stream) {
-  return L.p.precision == SFW_PRECISION_F64_STRICT ? sfw_launch_social_strict(L, stream) : sfw_launch_social(L, stream);
+hipError_t launch_social_of(const sfw_launch &L, hipStream_t stream, const sfw_split_streams *sp = nullptr) {
+  return L.p.precision == SFW_PRECISION_F64_STRICT ? sfw_launch_social_strict(L, stream, sp) : sfw_launch_social(L, stream, sp);
 }
 
 // SFW_DEVICE_CUS in the environment: pretend a device of that many compute units (planning heuristics only)
@@ -907,12 +909,12 @@ int launch_common(sfw_handle h) {
       L.col_src = tab + h->prefix_o_col_cls;
       L.in_state = h->cls_state[(n_lv - 1) & 1].p;
       L.in_dead = h->cls_dead[(n_lv - 1) & 1].p;
-      SFW_HIP(h, launch_social_of(L, h->stream));
+      SFW_HIP(h, launch_social_of(L, h->stream, &h->split));  // (`side` is idle: the stream has just waited for it)
     } else {
       if (!poses_done) SFW_HIP(h, sfw_launch_rollout_poses(L, h->stream));
       SFW_HIP(h, sfw_launch_rollout_costmap(L, h->stream));
       if (timing) SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
-      SFW_HIP(h, launch_social_of(L, h->stream));
+      SFW_HIP(h, launch_social_of(L, h->stream, &h->split));
     }
     if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c + 2], h->stream));
   }
@@ -1030,6 +1032,9 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_poses, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->split.fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->split.join, hipEventDisableTiming);
+  if (e == hipSuccess) h->split.side = h->side;
   for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
   if (e != hipSuccess) {
     sfw_destroy(h);
@@ -1081,6 +1086,8 @@ int sfw_destroy(sfw_handle h) {
     if (e) (void)hipEventDestroy(e);
   if (h->ev_poses) (void)hipEventDestroy(h->ev_poses);
   if (h->ev_side) (void)hipEventDestroy(h->ev_side);
+  if (h->split.fork) (void)hipEventDestroy(h->split.fork);
+  if (h->split.join) (void)hipEventDestroy(h->split.join);
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1360,6 +1367,7 @@ int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out) {
     out->chunks = chunk > 0 ? static_cast<int32_t>((T + chunk - 1) / chunk) : 0;
   }
   out->organisation = sfw_social_organisation(h->st_A, out->chunks > 0 ? (T + out->chunks - 1) / out->chunks : T, h->st_O, h->k2_form, h->n_cu);
+  out->flat_samples = sfw_social_flat_items(h->st_A, h->st_O, h->st_NG, out->chunks > 0 ? (T + out->chunks - 1) / out->chunks : T, h->k2_form, h->n_cu);
   return SFW_OK;
 }
 

@@ -129,6 +129,9 @@ struct sfw_launch {
   int32_t k2_form;               // SFW_K2_AUTO / _REGISTER / _FLAT: which organisation of a K2 wave (sfw_set_k2_form)
   int32_t n_cu, n_xcd;           // compute units / XCDs of the device (organisation thresholds, XCD-contiguous block order)
   int32_t n_cls, n_col_cls;      // PREFIX: classes of this level, its column classes
+  // K2 only: the launch covers the items [item_base, item_end) of the chunk / level (item_end 0: all of them) — one K2 pass
+  // may be split between the two organisations of a wave (sfw_launch_social, sfw_split_streams)
+  int64_t item_base, item_end;
   const int32_t *row_rep;        // PREFIX [row classes]  chunk-local row whose robot records represent the class
   const int32_t *col_rep;        // PREFIX [n_col_cls]    column likewise
   // where an item resumes from: record row_src[r] * n_col_src + col_src[c] of in_state, with (r, c) =
@@ -178,10 +181,18 @@ hipError_t sfw_launch_rollout(const sfw_launch &L, hipStream_t stream);  // = po
 // table), so the second can run beside it on another stream.
 hipError_t sfw_launch_rollout_poses(const sfw_launch &L, hipStream_t stream);
 hipError_t sfw_launch_rollout_costmap(const sfw_launch &L, hipStream_t stream);
-hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream);
+// sp (optional): a second stream and two events, with which a register-form launch whose waves do not divide evenly over
+// the SIMDs hands its last items to concurrent flat-form waves (bit-identical organisations; sfw_kernels.hip split_point)
+struct sfw_split_streams {
+  hipStream_t side;
+  hipEvent_t fork, join;
+};
+hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream, const sfw_split_streams *sp = nullptr);
 #ifndef SFW_STRICT_BUILD
 // the same launcher over the K2 kernels compiled with the longer polynomials (sfw_kernels_strict.hip): SFW_PRECISION_F64_STRICT
-hipError_t sfw_launch_social_strict(const sfw_launch &L, hipStream_t stream);
+// samples of a launch over T samples that the register form hands to flat-form waves (0: none)
+int64_t sfw_social_flat_items(int A, int O, int NG, int64_t T, int form, int cus);
+hipError_t sfw_launch_social_strict(const sfw_launch &L, hipStream_t stream, const sfw_split_streams *sp = nullptr);
 #endif
 // true when sfw_launch_rollout_poses runs all of K1 in one launch (small grids): the only form that writes L.points
 bool sfw_rollout_is_fused(const sfw_launch &L);

@@ -1336,8 +1336,8 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   const int GA = G * A;
   const int NG = GROUPS ? L.NG : 0;  // GROUPS=false instantiation: no group code, lean register budget
   const lds_layout s(smem, A, CAP, GA, G, O, NG, GROUPS ? L.n_grp_mem : 0, true, false);
-  const int64_t first_local = static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd))) * G;
-  const int64_t remain = item_count(L) - first_local;
+  const int64_t first_local = L.item_base + static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd))) * G;
+  const int64_t remain = (L.item_end > 0 ? L.item_end : item_count(L)) - first_local;
   const int Gn = remain < G ? static_cast<int>(remain) : G;
   const int step_begin = L.step_begin, step_end = L.step_end;
   const sfm_consts<R> k0 = make_consts<R, false>(L);  // the prologue's; every step builds its own (below)
@@ -1738,7 +1738,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
   (void)FCX;
   (void)FCY;
   const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, GROUPS, true, L.k.obs_lds != 0);
-  const int64_t first_local = xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd));
+  const int64_t first_local = L.item_base + xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd));
   const sfm_consts<R> k0 = make_consts<R, true>(L);  // the prologue's; every step builds its own (below)
   // the five force constants stay in scalar registers for the rollout (a step's copy into VGPRs is five v_mov; read from the
   // kernel arguments every step, a lone wave waited for the scalar loads at the top of each)
@@ -2437,16 +2437,66 @@ template <int CAP> static bool reg_layout_matches() {
          at(s.hasgoal) == off::HG && at(s.swp) == off::SW && at(s.dead) == off::DEAD && at(s.rsb) == off::RSB && s.hg_stride == 2;
 }
 
-template <typename R> static hipError_t launch_social_typed(const sfw_launch &L_in, hipStream_t stream) {
+// A register-form launch of W waves on S SIMDs keeps all its waves resident at once (up to six per SIMD), q = floor(W / S) on
+// every SIMD and one more on W mod S of them — and those set the duration: BASELINE cfg2's 5462 waves are 5.33 per SIMD and
+// take the time of 6 (VALU-active 75 %).  The organisations are bit-identical, so the launch may hand its last items to
+// flat-form waves — one sample each, about half the work of a register-form wave of three — that run beside exactly q
+// register-form waves per SIMD: cfg2's 16 384 samples = 5 x 1024 x 3 in the register form + 1024 flat waves, one per SIMD.
+// Returns how many of the `items` stay in the register form (all of them when a split would not pay; the costs are plan_for's
+// instruction counts per sample and step, plus 24 per laser-point evaluation).
+#ifndef SFW_SPLIT_FORMS
+#define SFW_SPLIT_FORMS 1
+#endif
+static int64_t split_point(const wave_plan &pl, int A, int O, int NG, int form, int64_t items, int cus) {
+  if (!SFW_SPLIT_FORMS || form != SFW_K2_AUTO || pl.flat || pl.ns != 1 || A < 2 || A > WAVE || NG > 0) return items;
+  const int64_t S = 4LL * cus, W = (items + pl.G - 1) / pl.G, q = W / S;
+  if (q < 1 || q > 5 || W % S == 0) return items;  // (six waves per SIMD are resident at once; beyond that the waves queue)
+  const int64_t reg_items = q * S * pl.G, rest = items - reg_items;
+  const int P = A * (A - 1) / 2, Lseg = (O + OBS_SEG - 1) / OBS_SEG;
+  const double c_reg_wave = 90.0 * (A / 2) + 225.0 + 24.0 * O;
+  const double c_flat_wave = 1.03 * (85.0 * ((P + WAVE - 1) / WAVE) + 215.0) + 24.7 * ((A + OBS_AGENT_LANES - 1) / OBS_AGENT_LANES) * Lseg;
+  const double t_now = static_cast<double>(q + 1), t_split = q + static_cast<double>((rest + S - 1) / S) * c_flat_wave / c_reg_wave;
+  return t_split < 0.97 * t_now ? reg_items : items;
+}
+
+// how many of the T samples of a launch the register form hands to flat-form waves (0: none; sfw_grid_plan_info)
+int64_t sfw_social_flat_items(int A, int O, int NG, int64_t T, int form, int cus) {
+  if (A <= 0 || T <= 0) return 0;
+  return T - split_point(plan_for(A, T, O, form, cus), A, O, NG, form, T, cus);
+}
+
+template <typename R> static hipError_t launch_social_typed(const sfw_launch &L_in, hipStream_t stream, const sfw_split_streams *sp = nullptr) {
   // The organisations are bit-identical and the class records of the shared-prefix rollout are
   // organisation-neutral, so every launch picks its own by its item count (measured: forcing the
   // flat form on an under-filled prefix phase at cfg2 — 2024 register-form waves — changes nothing).
-  const int64_t items = L_in.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L_in.n_cls) : L_in.chunk_count;
+  const int64_t all_items = L_in.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L_in.n_cls) : L_in.chunk_count;
+  const int64_t item_base = L_in.item_base, items = (L_in.item_end > 0 ? L_in.item_end : all_items) - item_base;
   const int cus = L_in.n_cu > 0 ? L_in.n_cu : SFW_DEFAULT_CUS;
   const wave_plan pl = plan_for(L_in.A, items, L_in.O, L_in.k2_form, cus);
+  if (sp && sp->side && item_base == 0 && L_in.item_end == 0) {
+    const int64_t keep = L_in.pair_tab ? split_point(pl, L_in.A, L_in.O, L_in.NG, L_in.k2_form, items, cus) : items;
+    if (keep < items) {
+      // the register-form part first (its waves take their q places per SIMD), the flat part beside it on the other stream
+      sfw_launch La = L_in, Lb = L_in;
+      La.item_end = keep;
+      La.k2_form = SFW_K2_REGISTER;
+      Lb.item_base = keep;
+      Lb.item_end = items;
+      Lb.k2_form = SFW_K2_FLAT;
+      Lb.clock_probe = nullptr;  // (one launch writes the clock probe)
+      hipError_t e = hipEventRecord(sp->fork, stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(sp->side, sp->fork, 0);
+      if (e == hipSuccess) e = launch_social_typed<R>(La, stream);
+      if (e == hipSuccess) e = launch_social_typed<R>(Lb, sp->side);
+      if (e == hipSuccess) e = hipEventRecord(sp->join, sp->side);
+      if (e == hipSuccess) e = hipStreamWaitEvent(stream, sp->join, 0);
+      return e;
+    }
+  }
   const unsigned grid = static_cast<unsigned>((items + pl.G - 1) / pl.G);
   sfw_launch L = L_in;
-  L.k.obs_lds = obs_in_lds(pl, L.A, L.O, L.NG, L.n_grp_mem, items, cus) ? 1 : 0;
+  // (the flat part of a split launch runs beside a full GPU: no LDS copy of the points, whatever its own item count)
+  L.k.obs_lds = (item_base == 0 && obs_in_lds(pl, L.A, L.O, L.NG, L.n_grp_mem, items, cus)) ? 1 : 0;
   const size_t lds = lds_bytes_for(pl, L.A, L.O, L.NG, L.n_grp_mem, L.k.obs_lds != 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static const bool layout_ok = reg_layout_matches<WAVE>() && reg_layout_matches<2 * WAVE>();
@@ -2504,16 +2554,16 @@ __global__ void __launch_bounds__(256) sfw_no_social_kernel(const sfw_launch L) 
 }
 }  // namespace
 
-hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream) {
+hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream, const sfw_split_streams *sp) {
   if (L.chunk_count <= 0 || L.A <= 0) return hipSuccess;
   if (SFW_SKIP_EMPTY_K2 && L.A == 1 && L.O == 0 && L.NG == 0 && L.phase != SFW_PHASE_PREFIX && !L.out_state) {
     hipLaunchKernelGGL(sfw_no_social_kernel, dim3(static_cast<unsigned>((L.chunk_count + 255) / 256)), dim3(256), 0, stream, L);
     return hipGetLastError();
   }
 #ifndef SFW_STRICT_BUILD  // (the strict build of this file holds the f64 kernels only)
-  if (L.p.precision == SFW_PRECISION_F32) return launch_social_typed<float>(L, stream);
+  if (L.p.precision == SFW_PRECISION_F32) return launch_social_typed<float>(L, stream, sp);
 #endif
-  return launch_social_typed<double>(L, stream);
+  return launch_social_typed<double>(L, stream, sp);
 }
 
 hipError_t sfw_launch_key_table(const sfw_sel *sel, double *table, int r, int R, hipStream_t stream) {

@@ -11,6 +11,7 @@
 #define sfw_samples_per_wave sfw_strict_unused_samples_per_wave
 #define sfw_social_organisation sfw_strict_unused_social_organisation
 #define sfw_derive sfw_strict_unused_derive
+#define sfw_social_flat_items sfw_strict_unused_social_flat_items
 #define sfw_social_lds_bytes sfw_strict_unused_social_lds_bytes
 #define sfw_pair_table_entries sfw_strict_unused_pair_table_entries
 #define sfw_launch_pair_table sfw_strict_unused_launch_pair_table

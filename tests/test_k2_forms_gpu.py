@@ -267,3 +267,45 @@ def test_task_loop_edge_sizes(hip_mod, n_obs, filling):
                 assert g.plan_info()["organisation"] == SFW_ORG_FLAT
         assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1], (n_people, n_obs, filling)
         assert (res[0][0] >= 0).any()
+
+
+# (i) a register-form launch whose waves do not divide evenly over the SIMDs hands its last samples to flat-form waves on a
+#     second stream (sfw_launch_social, split_point): BASELINE cfg2's 16 384 samples = 5 x 1024 waves of three + 1024 flat
+#     waves.  What the plan says, and that neither the split nor the device shape it is computed for shows in any cost.
+def test_split_launch_between_the_organisations(hip_mod, monkeypatch):
+    monkeypatch.delenv("SFW_DEVICE_CUS", raising=False)
+    w = syn.WORKLOADS["cfg2"]
+    scene = syn.make_scene(w)
+    kw = dict(sim_time=w.sim_time, sim_granularity=w.sim_granularity)
+    res = {}
+    for form in (SFW_K2_AUTO, SFW_K2_REGISTER, SFW_K2_FLAT):
+        g = hip_mod.HipScorer(default_params(**kw))
+        g.set_k2_form(form)
+        g.load_scene(scene)
+        res[form] = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+        info = g.plan_info()
+        if form == SFW_K2_AUTO:
+            auto_info = info
+        else:
+            assert info["flat_samples"] == 0, info  # a forced organisation is never split
+    assert auto_info["organisation"] == SFW_ORG_REGISTER_1
+    import torch
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:  # a whole MI355X: 1024 SIMDs
+        assert auto_info["flat_samples"] == 1024, auto_info
+    for form in (SFW_K2_REGISTER, SFW_K2_FLAT):
+        assert np.array_equal(res[SFW_K2_AUTO][0], res[form][0]) and res[SFW_K2_AUTO][1] == res[form][1]
+    # a pretended 32-CU device (128 SIMDs): 20 x 101 = 2020 samples of 21 agents = 5 x 128 x 3 + 100
+    monkeypatch.setenv("SFW_DEVICE_CUS", "32")
+    w2 = dataclasses.replace(w, nv=20, nw=101)
+    scene2 = syn.make_scene(w2)
+    out = {}
+    for form in (SFW_K2_AUTO, SFW_K2_REGISTER, SFW_K2_FLAT):
+        g = hip_mod.HipScorer(default_params(**kw))
+        g.set_k2_form(form)
+        g.load_scene(scene2)
+        out[form] = g.score_grid(scene2.robot_state, scene2.linvels, scene2.angvels, scene2.goal_args)
+        if form == SFW_K2_AUTO:
+            info = g.plan_info()
+            assert info["organisation"] == SFW_ORG_REGISTER_1 and info["flat_samples"] == 100, info
+    for form in (SFW_K2_REGISTER, SFW_K2_FLAT):
+        assert np.array_equal(out[SFW_K2_AUTO][0], out[form][0]) and out[SFW_K2_AUTO][1] == out[form][1]
