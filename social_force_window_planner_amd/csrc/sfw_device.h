@@ -129,9 +129,9 @@ struct sfw_launch {
   int32_t k2_form;               // SFW_K2_AUTO / _REGISTER / _FLAT: which organisation of a K2 wave (sfw_set_k2_form)
   int32_t n_cu, n_xcd;           // compute units / XCDs of the device (organisation thresholds, XCD-contiguous block order)
   int32_t n_cls, n_col_cls;      // PREFIX: classes of this level, its column classes
-  // K2 only: the launch covers the items [item_base, item_end) of the chunk / level (item_end 0: all of them) — one K2 pass
-  // may be split between the two organisations of a wave (sfw_launch_social, sfw_split_streams)
-  int64_t item_base, item_end;
+  // flat K2 only: the launch covers the items from item_base on (0: all of them) — a register-form launch may hand its last
+  // items to flat-form waves (sfw_launch_social, sfw_split_streams)
+  int32_t item_base;
   const int32_t *row_rep;        // PREFIX [row classes]  chunk-local row whose robot records represent the class
   const int32_t *col_rep;        // PREFIX [n_col_cls]    column likewise
   // where an item resumes from: record row_src[r] * n_col_src + col_src[c] of in_state, with (r, c) =

@@ -1336,8 +1336,8 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   const int GA = G * A;
   const int NG = GROUPS ? L.NG : 0;  // GROUPS=false instantiation: no group code, lean register budget
   const lds_layout s(smem, A, CAP, GA, G, O, NG, GROUPS ? L.n_grp_mem : 0, true, false);
-  const int64_t first_local = L.item_base + static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd))) * G;
-  const int64_t remain = (L.item_end > 0 ? L.item_end : item_count(L)) - first_local;
+  const int64_t first_local = static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd))) * G;
+  const int64_t remain = item_count(L) - first_local;
   const int Gn = remain < G ? static_cast<int>(remain) : G;
   const int step_begin = L.step_begin, step_end = L.step_end;
   const sfm_consts<R> k0 = make_consts<R, false>(L);  // the prologue's; every step builds its own (below)
@@ -2470,18 +2470,20 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L_
   // organisation-neutral, so every launch picks its own by its item count (measured: forcing the
   // flat form on an under-filled prefix phase at cfg2 — 2024 register-form waves — changes nothing).
   const int64_t all_items = L_in.phase == SFW_PHASE_PREFIX ? static_cast<int64_t>(L_in.n_cls) : L_in.chunk_count;
-  const int64_t item_base = L_in.item_base, items = (L_in.item_end > 0 ? L_in.item_end : all_items) - item_base;
+  const int64_t item_base = L_in.item_base, items = all_items - item_base;  // (item_base > 0: the flat part of a split launch)
   const int cus = L_in.n_cu > 0 ? L_in.n_cu : SFW_DEFAULT_CUS;
   const wave_plan pl = plan_for(L_in.A, items, L_in.O, L_in.k2_form, cus);
-  if (sp && sp->side && item_base == 0 && L_in.item_end == 0) {
+  if (sp && sp->side && item_base == 0) {
     const int64_t keep = L_in.pair_tab ? split_point(pl, L_in.A, L_in.O, L_in.NG, L_in.k2_form, items, cus) : items;
     if (keep < items) {
       // the register-form part first (its waves take their q places per SIMD), the flat part beside it on the other stream
+      // (the register-form kernel is left as it is — a bound of its own cost its strict build 36 bytes of scratch —: its part
+      // is a launch over the first `keep` items; the flat kernel takes the first item of its part from item_base)
       sfw_launch La = L_in, Lb = L_in;
-      La.item_end = keep;
+      if (La.phase == SFW_PHASE_PREFIX) La.n_cls = static_cast<int32_t>(keep);
+      else La.chunk_count = keep;
       La.k2_form = SFW_K2_REGISTER;
-      Lb.item_base = keep;
-      Lb.item_end = items;
+      Lb.item_base = static_cast<int32_t>(keep);
       Lb.k2_form = SFW_K2_FLAT;
       Lb.clock_probe = nullptr;  // (one launch writes the clock probe)
       hipError_t e = hipEventRecord(sp->fork, stream);
