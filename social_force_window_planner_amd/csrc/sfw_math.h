@@ -18,7 +18,7 @@ namespace sfwm {
 #define SFW_ASIN_DEG 7
 #endif
 #ifndef SFW_EXP_DEG
-#define SFW_EXP_DEG 8
+#define SFW_EXP_DEG 9
 #endif
 // asin(n) = n * Q(n*n), |n| <= sin(pi/8)
 #if SFW_ASIN_DEG == 8  // max abs err 2.3e-15

@@ -90,23 +90,24 @@ def isa_loops():
 
 
 def test_pair_loop_instruction_counts(isa_loops):
-    """Flat form: the loop body holds two 64-pair iterations (8 + 8 state reads, 4 + 4 atomics, 4 rsq): <= 85 VALU instructions per
-    pair.  Register form: one partner per iteration, 2 rsq, the partner's state through LDS: <= 90."""
+    """Flat form: the loop body holds two 64-pair iterations (8 + 8 state reads, 4 + 4 atomics, 4 rsq): <= 87 VALU instructions per
+    pair.  Register form: one partner per iteration, 2 rsq, the partner's state through LDS: <= 92.  (Round 5: the default
+    build's exponential is the degree-9 polynomial — one more fma in each of the pair term's two Horner chains than rounds 3-4.)"""
     flat = [l for l in isa_loops["flat"] if l["trans"] == 4 and l["ds"] == 24]
-    assert len(flat) == 1 and flat[0]["valu"] <= 170, isa_loops["flat"]
+    assert len(flat) == 1 and flat[0]["valu"] <= 174, isa_loops["flat"]
     reg = [l for l in isa_loops["reg"] if l["trans"] == 2 and l["ds"] >= 8 and l["valu"] < 120]
-    assert len(reg) == 1 and reg[0]["valu"] <= 90, isa_loops["reg"]
+    assert len(reg) == 1 and reg[0]["valu"] <= 92, isa_loops["reg"]
 
 
 def test_laser_point_loop_instruction_counts(isa_loops):
-    """24 VALU instructions per (agent, point), one of them v_rsq_f64.  The flat form's task loops with wave-uniform trip counts
+    """25 VALU instructions per (agent, point) (24 until round 4: the exponential's degree 9), one of them v_rsq_f64.  The flat form's task loops with wave-uniform trip counts
     carry no other vector instruction (global-memory loops: 2 points x 1..4 agents per iteration, 2 loads) or three per
     iteration (LDS copy); the register form's scalar loop: 4 points per s_load_dwordx16."""
     obs = isa_loops["flat_obs"]
     for nj in (1, 2, 3, 4):
-        g = [l for l in obs if l["trans"] == 2 * nj and l["vmem"] == 2 and l["ds"] == 0 and l["f64"] == 48 * nj]
-        assert g and all(l["valu"] == 48 * nj for l in g), (nj, obs)
-        lds = [l for l in obs if l["trans"] == 2 * nj and l["vmem"] == 0 and l["ds"] == 2 and l["f64"] == 48 * nj]
-        assert lds and all(l["valu"] <= 48 * nj + 3 for l in lds), (nj, obs)
+        g = [l for l in obs if l["trans"] == 2 * nj and l["vmem"] == 2 and l["ds"] == 0 and l["f64"] == 50 * nj]
+        assert g and all(l["valu"] == 50 * nj for l in g), (nj, obs)
+        lds = [l for l in obs if l["trans"] == 2 * nj and l["vmem"] == 0 and l["ds"] == 2 and l["f64"] == 50 * nj]
+        assert lds and all(l["valu"] <= 50 * nj + 3 for l in lds), (nj, obs)
     reg = [l for l in isa_loops["reg"] if l["trans"] == 4 and l["ds"] == 0 and l["vmem"] == 0]
-    assert reg and all(l["valu"] == 96 for l in reg), isa_loops["reg"]
+    assert reg and all(l["valu"] == 100 for l in reg), isa_loops["reg"]
