@@ -72,6 +72,9 @@ def parse_args():
     ap.add_argument("--verify-budget", type=float, default=75.0,
                     help="seconds of all-core oracle time the verify leg may take: the WHOLE grid when it fits (the target "
                          "grid: ~30 s on the 256-thread GPU box), else a sub-grid spread over the whole grid")
+    ap.add_argument("--extra-verify-budget", type=float, default=6.0,
+                    help="seconds of all-core oracle time the verify leg of EACH entry under `extra` may take (cfg2's whole grid "
+                         "fits; the others: a sub-grid + the 32 lowest-cost samples); 0 switches those legs off")
     ap.add_argument("--resident", action="store_true",
                     help="time launch + selection fetch only (no stage, no cost-vector D2H): kernel tuning aid")
     return ap.parse_args()
@@ -133,11 +136,14 @@ def cpu_baseline(scene, params_kw, budget_s=12.0):
     }
 
 
-def verify_against_oracle(job, costs, best, budget_s, global_key=None):
+def verify_against_oracle(job, costs, best, budget_s, global_key=None, topk=0, tol=1e-9):
     """The launch bench.py times, checked against the CPU oracle OUTSIDE the timed region: the whole grid of this rank when
     the oracle finishes it within budget_s on all host threads, otherwise a sub-grid spread evenly over the whole grid.
-    Compared: sentinel sets (-1 rejected, -2 the never-scored (0,0) sample), every valid cost (max relative error), and —
-    whole grid only — the selection: index, vx, vtheta, n_valid (ref src/sfw_planner.cpp:394-414)."""
+    Compared: sentinel sets (-1 rejected, -2 the never-scored (0,0) sample), every valid cost (max relative error), and the
+    selection (ref src/sfw_planner.cpp:394-414): on a whole grid index, vx, vtheta and n_valid against the oracle's own
+    sequential scan; on a sub-grid (topk > 0) the oracle also scores the topk samples the launch ranks lowest, and the
+    reference's selection order over everything the oracle scored must name the launch's sample (cmd_vel_scope says which
+    of the two a line's cmd_vel_match is)."""
     from oracle.sfw_oracle import OracleScorer
     from social_force_window_planner_amd._abi import default_params
 
@@ -185,6 +191,7 @@ def verify_against_oracle(job, costs, best, budget_s, global_key=None):
                                     and best["vtheta"] == ob["vtheta"] and best["n_valid"] == ob["n_valid"])
         out["oracle_cmd_vel"] = {"vx": ob["vx"], "vtheta": ob["vtheta"], "cost": ob["cost"], "index": ob["index"] + job.index_base,
                                  "n_valid": ob["n_valid"]}
+        out["cmd_vel_scope"] = "the oracle's sequential selection over the whole grid"
     if not whole or global_key:
         # the selected sample itself, wherever it lies: its cost under the oracle, and that no checked sample beats it
         gi = int(-global_key[3]) if global_key else best["index"]
@@ -194,6 +201,47 @@ def verify_against_oracle(job, costs, best, budget_s, global_key=None):
             gcost = global_key[0] if global_key else best["cost"]
             out["selected_sample"] = {"index": gi, "oracle_cost": float(c1[0]), "rel_err": float(abs(c1[0] - gcost) / abs(c1[0])),
                                       "no_sampled_cost_below_it": bool(not v.any() or oc[v].min() >= c1[0] * (1 - 1e-9))}
+    if not whole and topk > 0 and not global_key:
+        # The selection on a grid the oracle cannot finish: the oracle scores the topk samples the launch ranks lowest as well
+        # (row by row, all threads), and the reference's order (cost up, linvel down, |angvel| up, later iterate first; the
+        # 10000.0 cap) over everything the oracle scored — sub-grid + those — must name the launch's sample.
+        flat = np.asarray(costs)
+        sel = (flat >= 0) & (flat <= 10000.0)
+        cand = np.flatnonzero(sel)
+        cand = cand[np.argsort(flat[cand], kind="stable")[:topk]]
+        if best["index"] - job.index_base >= 0 and best["index"] - job.index_base not in cand:
+            cand = np.append(cand, best["index"] - job.index_base)
+        keys = {}
+        for ri, r in enumerate(rows):  # the sub-grid's oracle costs
+            for ci, c in enumerate(cols):
+                keys[int(r) * len(ang) + int(c)] = float(oc[ri * len(cols) + ci])
+        top_rel = 0.0
+        for r in np.unique(cand // len(ang)):
+            cs = np.sort(cand[cand // len(ang) == r] % len(ang))
+            c_or, _ = o.score_grid(rs, lin[r:r + 1], ang[cs], ga, n_threads=min(cores, len(cs)))
+            for c, val in zip(cs, c_or):
+                keys[int(r) * len(ang) + int(c)] = float(val)
+                g = flat[int(r) * len(ang) + int(c)]
+                if val >= 0:
+                    top_rel = max(top_rel, abs(g - val) / abs(val))
+                else:
+                    same_set = False
+        pick, pk = -1, None
+        for i, cst in keys.items():
+            if cst < 0 or cst > 10000.0:
+                continue
+            r, c = divmod(i, len(ang))
+            k = (cst, -float(lin[r]), abs(float(ang[c])), -i)
+            if pk is None or k < pk:
+                pick, pk = i, k
+        out["invalid_set_equal"] = same_set
+        out["max_rel_err"] = max(out["max_rel_err"], top_rel)
+        out["cmd_vel_match"] = bool(pick == best["index"] - job.index_base)
+        out["cmd_vel_scope"] = (f"the reference's selection order over the {len(keys)} samples the oracle scored: the sub-grid + the "
+                                f"{len(cand)} samples the launch ranks lowest")
+        out["oracle_cmd_vel"] = {"index": pick + job.index_base if pick >= 0 else -1, "cost": pk[0] if pk else -1.0}
+    out["within_tolerance"] = bool(out["max_rel_err"] <= tol and out["invalid_set_equal"])
+    out["tolerance_checked"] = tol
     return out
 
 
@@ -443,7 +491,7 @@ def host_wait(dist, rank, key):
 
 def measured_traffic(workload_name):
     """HBM bytes per launch from the committed PMC passes (profiles/r0N_traffic.json, newest first), or None."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f).get(workload_name)
@@ -524,11 +572,24 @@ def workload_text(w):
             + (f", pedestrians from {w.people_r_in} m (SURVEY §8d's crowd as specified)" if w.n_people >= 150 and w.people_r_in is not None else ""))
 
 
-def extra_entry(name, precision, steps, warmup, ctx):
+def brief_verify(job, timed_best, precision, budget_s):
+    """One more call of the job the entry has just timed, its cost vector against the oracle under the entry's budget
+    (verify_against_oracle: the whole grid when that fits, else a sub-grid + the 32 lowest-cost samples for the selection)."""
+    costs, vbest, _ = job.step()
+    v = verify_against_oracle(job, costs, vbest, budget_s, topk=32, tol=1e-4 if precision == "f32" else 1e-9)
+    return {"samples": v["samples"], "coverage": v["coverage"], "max_rel_err": v["max_rel_err"],
+            "invalid_set_equal": v["invalid_set_equal"], "cmd_vel_match": v["cmd_vel_match"], "cmd_vel_scope": v.get("cmd_vel_scope"),
+            "within_tolerance": v["within_tolerance"], "tolerance_checked": v["tolerance_checked"],
+            "same_cmd_vel_as_timed_steps": vbest["index"] == timed_best["index"], "oracle_seconds": v["oracle"]["seconds"]}
+
+
+def extra_entry(name, precision, steps, warmup, ctx, verify_budget=0.0):
     r = run_config(name, precision, steps, warmup, ctx)
     j = r["job"]
     rf = roofline_for(j, r["k2_ms"], precision, brief=True)
+    ver = brief_verify(j, r["best"], precision, verify_budget) if verify_budget > 0 else None
     return {
+        "verify": ver,
         "workload": workload_text(j.workload),
         "value": r["n_scored_total"] * steps / r["elapsed"],
         "unit": "trajectories/s",
@@ -731,13 +792,14 @@ def main():
                 "value": r_res["n_scored_total"] * r_res["steps"] / r_res["elapsed"], "unit": "trajectories/s",
                 "ms_per_step": r_res["elapsed"] / r_res["steps"] * 1e3,
                 "note": "launch + 48-byte selection fetch only, grid staged once (round-1 headline form)"}
+        evb = 0.0 if args.no_verify else args.extra_verify_budget
         for name in ("cfg2", "cfg2_o64", "cfg2_o240", "target_o720", "cfg3", "cfg4"):
             if name in wanted and name != args.workload:
-                extra[name] = extra_entry(name, args.precision, args.extra_steps, 2, ctx)
+                extra[name] = extra_entry(name, args.precision, args.extra_steps, 2, ctx, evb)
                 if name == "cfg4" and "cfg4_spec" in wanted:
                     # SURVEY §8d's cfg4 crowd as specified: no sample reaches the horizon without a pedestrian contact (n_valid
                     # 0), so this entry times rollouts that end early — reported so that the specified workload has a number
-                    e = extra_entry("cfg4_spec", args.precision, max(3, args.extra_steps // 4), 1, ctx)
+                    e = extra_entry("cfg4_spec", args.precision, max(3, args.extra_steps // 4), 1, ctx, evb)
                     for k in ("roofline_frac", "roofline_executed_frac"):
                         e.pop(k, None)
                     e["note"] = ("every sample ends in a pedestrian contact before the horizon (n_valid 0, no cmd_vel): rollouts "
@@ -752,15 +814,17 @@ def main():
                     "value": r3["n_scored_total"] * st / r3["elapsed"], "unit": "trajectories/s",
                     "kernel_ms": {"social": r3["k2_ms"]},
                     "same_cmd_vel_as_f64": r3["best"]["index"] == out["cmd_vel"]["index"],
+                    "verify": brief_verify(r3["job"], r3["best"], "f32", evb) if evb > 0 else None,
                     "note": "not the headline: costs within 1e-4 (measured <= 3e-5) of the f64 oracle on the BASELINE "
-                            "workloads (0.025 s steps); chaotic 0.25 s-step crowds differ more (profiles/r04_parity_sweep.txt)"}
+                            "workloads (0.025 s steps); chaotic 0.25 s-step crowds differ more (profiles/r05_parity_sweep.txt)"}
                 # the other opt-in: f64 with the pair term's polynomials one degree longer each (SFW_PRECISION_F64_STRICT)
                 rs_ = run_config(args.workload, "f64_strict", st, 1, ctx)
                 extra["f64_strict_mode"] = {
                     "value": rs_["n_scored_total"] * st / rs_["elapsed"], "unit": "trajectories/s",
                     "kernel_ms": {"social": rs_["k2_ms"]},
                     "same_cmd_vel_as_f64": rs_["best"]["index"] == out["cmd_vel"]["index"],
-                    "note": "asin 8 / exp 9 instead of 7 / 8: the pair term at ~1e-14 instead of ~1e-12 relative"}
+                    "verify": brief_verify(rs_["job"], rs_["best"], "f64_strict", evb) if evb > 0 else None,
+                    "note": "asin 8 / exp 9 instead of the default's 7 / 9 (7 / 8 until round 4): the angle's polynomial one degree longer"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(_scene_with_grid(job), job.params_kw)
     if extra:

@@ -63,6 +63,12 @@ def test_single_gpu_line():
     assert vf["samples"] == 65536 and vf["coverage"].startswith("the whole grid")
     assert vf["invalid_set_equal"] is True and vf["cmd_vel_match"] is True and vf["max_rel_err"] <= 1e-9
     assert vf["oracle_cmd_vel"]["index"] == d["cmd_vel"]["index"] and vf["same_cmd_vel_as_timed_steps"] is True
+    # ... and every timed entry of `extra` carries its own: cfg2's whole grid, the laser-point variants inside --extra-verify-budget
+    for name in ("cfg2", "cfg2_o64", "cfg2_o240"):
+        ev = ex[name]["verify"]
+        assert ev["invalid_set_equal"] is True and ev["cmd_vel_match"] is True and ev["max_rel_err"] <= 1e-9, (name, ev)
+        assert ev["within_tolerance"] is True and ev["same_cmd_vel_as_timed_steps"] is True, (name, ev)
+    assert ex["cfg2"]["verify"]["coverage"].startswith("the whole grid") and ex["cfg2"]["verify"]["samples"] == 16384
     # the per-cycle world upload is outside the timed step; the line says so and prices it
     assert "world_state" in d["config"] and 0 < d["value_incl_world_upload"] < d["value"]
     assert "240 laser points" in ex["cfg2_o240"]["workload"] and ex["cfg2_o240"]["value"] < ex["cfg2_o64"]["value"]
