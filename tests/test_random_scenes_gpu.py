@@ -87,11 +87,17 @@ def oracle_sensitivity(oracle_mod, scene, p, rs, ga, lin, ang, base, eps=2e-14, 
     return worst
 
 
-# The kernels' own error against the oracle's libm is ~1e-12 relative per force term (exp2 polynomial 1.1e-12, asin 5.4e-14;
-# csrc/sfw_math.h) = 50 x the 2e-14 the probe injects: a scene may exceed 1e-9 by at most that factor over the oracle's OWN
-# response to the probe (round 3 allowed 1e4 x).  Seeds that needed the allowance are collected and bounded below.
+# Where a scene may exceed 1e-9 at all: ONLY with explicit Euler steps above 0.05 s (the 0.25 s third of the seeds), where
+# crowds of 30+ agents are chaotic.  There the excess is bounded by CHAOS_FACTOR x the oracle's OWN response
+# to a 2e-14 probe (the kernels' error per force term is of that order: exp2 polynomial 1.8e-14 since round 5, asin 5.4e-14,
+# Newton-refined roots 1.4e-14; csrc/sfw_math.h) AND, with the lightsfm default parameters — the reference's regime, two
+# seeds of three — by the north star's 1e-4 whatever the oracle's response is.  Seeds with steps of at most 0.05 s get no
+# allowance.  The seeds that took the allowance are collected; the 40 seeds of this test need it for none (round 4: none
+# either; the 3000-seed sweeps find ~1 % of the scenes in that regime, profiles/r05_parity_sweep.txt).
 CHAOS_FACTOR = 50.0
-CHAOS_SEEDS_MAX = 2  # of 40 (the 3000-seed sweeps find ~1 % of the scenes in that regime, profiles/r04_parity_sweep.txt)
+CHAOS_SEEDS_MAX = 0
+WELL_CONDITIONED_GRAN = 0.05
+NORTH_STAR_REL = 1e-4
 _chaotic_seeds = []
 
 
@@ -109,19 +115,28 @@ def test_random_scene(oracle_mod, hip_mod, seed):
     v = oc >= 0
     if v.any():
         rel = np.abs(gc[v] - oc[v]) / np.maximum(np.abs(oc[v]), 1e-300)
-        if rel.max() > 1e-9:  # only legitimate for a chaotic scene: bounded by the oracle's own conditioning
+        gran = scene.workload.sim_granularity
+        if gran <= WELL_CONDITIONED_GRAN:  # the BASELINE workloads' regime: 1e-9, no allowance
+            assert rel.max() <= 1e-9, f"seed {seed} (steps of {gran} s): max rel err {rel.max():.3e}"
+        elif rel.max() > 1e-9:  # only legitimate for a chaotic scene: bounded by the oracle's own conditioning
             sens = oracle_sensitivity(oracle_mod, scene, p, rs, ga, lin, ang, oc)
-            _chaotic_seeds.append((seed, float(rel.max()), sens))
+            _chaotic_seeds.append((seed, float(rel.max()), sens, seed % 3 != 0))
             print(f"chaotic scene, seed {seed}: max rel err {rel.max():.3e}, oracle response to 2e-14 noise {sens:.3e}")
             assert rel.max() <= CHAOS_FACTOR * sens, f"seed {seed}: max rel err {rel.max():.3e}, oracle response to 2e-14 noise {sens:.3e}"
+            if seed % 3 != 0:  # lightsfm defaults: the north star's bound holds whatever the conditioning
+                assert rel.max() <= NORTH_STAR_REL, f"seed {seed} (default lightsfm parameters): max rel err {rel.max():.3e}"
     assert gb["index"] == ob["index"] and gb["n_valid"] == ob["n_valid"]
     assert gb["vx"] == ob["vx"] and gb["vtheta"] == ob["vtheta"]
 
 
 def test_random_scene_chaos_allowance_is_rare():
-    """How many of the 40 seeds above needed the chaos allowance (runs after them; printed with pytest -rA)."""
-    print(f"seeds over 1e-9 that took the chaos allowance: {len(_chaotic_seeds)} of 40: {_chaotic_seeds}")
+    """How many of the 40 seeds above needed the chaos allowance (runs after them; printed with pytest -rA), the largest
+    deviation among them, and that none with the lightsfm default parameters left the north star's 1e-4."""
+    worst = max((r for _, r, _, _ in _chaotic_seeds), default=0.0)
+    print(f"seeds over 1e-9 that took the chaos allowance: {len(_chaotic_seeds)} of 40 (allowed {CHAOS_SEEDS_MAX}), "
+          f"largest deviation {worst:.3e}: {_chaotic_seeds}")
     assert len(_chaotic_seeds) <= CHAOS_SEEDS_MAX, _chaotic_seeds
+    assert all(r <= NORTH_STAR_REL for _, r, _, dflt in _chaotic_seeds if dflt), _chaotic_seeds
 
 
 def _case_standing(seed):
