@@ -71,6 +71,17 @@ ControllerParams SFWPlannerNode::readControllerParams() {
   // term's polynomials one degree longer), "f32" (forces in float)
   const std::string precision = param<std::string>(n, p + "device_precision", "f64");
   c.precision_ = precision == "f32" ? SFW_PRECISION_F32 : precision == "f64_strict" ? SFW_PRECISION_F64_STRICT : SFW_PRECISION_F64;
+  if (precision != "f64" && precision != "f32" && precision != "f64_strict")
+    RCLCPP_WARN(node_->get_logger(), "%sdevice_precision: unknown value '%s' (f64, f64_strict, f32): using f64", p.c_str(), precision.c_str());
+  // Declared by the reference (sfw_planner.hpp:122-125, :136-138, :149-156) and read by nothing in it — scoreTrajectory takes
+  // the step count from sim_granularity alone (:517 is a comment), the people's radius from the sensor interface's
+  // person_radius, the force factors from lightsfm's own defaults — so they are declared here too, for a yaml written for the
+  // reference (config/local_planner.yaml:20-26) to load without "undeclared parameter" complaints, and likewise ignored.
+  (void)param(n, p + "angular_sim_granularity", 0.025);
+  (void)param(n, p + "people_radius", 0.35);
+  (void)param(n, p + "sfm_goal_weight", 2.0);
+  (void)param(n, p + "sfm_obstacle_weight", 20.0);
+  (void)param(n, p + "sfm_people_weight", 12.0);
   return c;
 }
 // Parameter names exactly as reference sensor_interface.hpp:78-124.
