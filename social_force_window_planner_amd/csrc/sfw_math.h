@@ -137,7 +137,10 @@ struct poly_consts {
 __device__ __forceinline__ void fp_mode_for_omod() {
 #if SFW_OMOD
   // MODE[7:6] = FP_DENORM of f64 / f16: 0 = flush inputs and outputs; MODE[9] = IEEE
-  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0");
+  // "memory": no load moves across the switch, so nothing derived from a load — every norm's operand is — is computed in
+  // front of it (the fma below is an ordinary asm and carries no dependency of its own on the mode; tools/isa_asm_hazards.py,
+  // run by tests/test_kernel_resources.py, checks on the ISA that every kernel holding such an fma switches the mode first)
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0" ::: "memory");
 #endif
 }
 // v_rsq_f64 / v_rcp_f64 deliver ~23 good bits; one Newton step gives ~46.

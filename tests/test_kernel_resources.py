@@ -85,7 +85,8 @@ def isa_loops():
                     res.append(dict(zip(("valu", "f64", "trans", "salu", "ds", "vmem"), map(int, m.groups()))))
             return res
 
-        yield {"flat": loops("sfw_social_kernel_flatIdLb0ELi64ELb0E"), "flat_obs": loops("sfw_social_kernel_flatIdLb0ELi64ELb1E"),
+        hz = subprocess.run(["python3", os.path.join(ROOT, "tools", "isa_asm_hazards.py"), asm], capture_output=True, text=True, timeout=300)
+        yield {"hazards": (hz.returncode, hz.stdout), "flat": loops("sfw_social_kernel_flatIdLb0ELi64ELb0E"), "flat_obs": loops("sfw_social_kernel_flatIdLb0ELi64ELb1E"),
                "reg": loops("sfw_social_kernelIdLi1ELb0E")}
 
 
@@ -111,3 +112,14 @@ def test_laser_point_loop_instruction_counts(isa_loops):
         assert lds and all(l["valu"] <= 50 * nj + 3 for l in lds), (nj, obs)
     reg = [l for l in isa_loops["reg"] if l["trans"] == 4 and l["ds"] == 0 and l["vmem"] == 0]
     assert reg and all(l["valu"] == 100 for l in reg), isa_loops["reg"]
+
+
+def test_inline_asm_idioms_hold_in_the_whole_isa(isa_loops):
+    """What the compiler cannot check about the kernels' inline asm (tools/isa_asm_hazards.py, whole functions — preheaders and
+    exits, not just loop bodies): no instruction touches the destination of an asm-issued load (obs_load_ahead,
+    load_pair_entries) between the load and the s_waitcnt that covers it, and every kernel with an output-modifier fma
+    (`v_fma_f64 ... div:2`, sfw_math.h) switches the MODE register in front of the first one."""
+    rc, out = isa_loops["hazards"]
+    assert rc == 0, out[-3000:]
+    m = re.search(r"(\d+) asm-issued loads checked, (\d+) functions with an output-modifier fma, 0 violation", out)
+    assert m and int(m.group(1)) > 100 and int(m.group(2)) >= 20, out[-500:]
