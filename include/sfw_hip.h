@@ -120,13 +120,16 @@ typedef struct sfw_agent {
   double desired_velocity; /* Agent::desiredVelocity.  <= 0 is accepted, as
                               the reference accepts people_velocity_ = 0
                               (sensor_interface.cpp:503): the speed clamp of
-                              updatePosition pins such a person where it
-                              stands.  With a stopped robot (or its like) it
-                              is at exact relative rest at EVERY step; the
-                              angular term of such a pair is exactly 0 here
-                              where lightsfm's sign(theta) is the rounding
-                              noise of two atan2 (-1, 0 or +1): reproduced
-                              for the handed-over state only */
+                              updatePosition pins a person with 0 where it
+                              stands.  Next to a robot without twist it is
+                              at exact relative rest at EVERY step, where
+                              lightsfm's sign(theta) is the rounding noise of
+                              two atan2 (-1, 0 or +1): reproduced for the
+                              handed-over state and for a robot that stands
+                              still from the start (the linvel = 0 samples),
+                              NOT for one that brakes to a stop during the
+                              rollout — the angular term of that pair is 0
+                              from there on                  */
   double radius;           /* Agent::radius                                 */
   int32_t has_goal;        /* goals non-empty (people: 1, robot at t0: 0)   */
   int32_t id;              /* Agent::id — the robot-on-person force skips a

@@ -117,6 +117,11 @@ struct sfw_planner_s {
   // ordered pairs (i, j) of agents with w x diff == 0 at hand-over (standing people, collinear walkers): see rest_forces
   std::vector<std::pair<int32_t, int32_t>> rest_pairs;
   const double *d_agent_rest = nullptr;  // A x (fx, fy) in `world`, or null when there is no such pair
+  const double *d_pin_rest = nullptr;  // see pinned_rest_table: the stage's table on the device, or null
+  bool pin_rest_on = true;             // SFW_PIN_REST=0 in the environment of sfw_create: no such table (tests: what it changes)
+  size_t st_pin_doubles = 0;           // its length (4 + A) when the last stage built one
+  std::vector<double> st_pin_pos;      // ... and what it was built from (sfw_set_params between stage and launch rebuilds it)
+  std::vector<sfw_agent_const> st_pin_cst;
   std::vector<std::pair<int32_t, int32_t>> st_rest_pairs;  // what the last stage evaluated them from: sfw_set_params
   std::vector<double> st_rest_pv;                           // between stage and launch re-evaluates (pos | vel, 4A doubles)
   // what the last stage uploaded (sfw_set_* after a stage take effect at the next stage; a launch
@@ -286,6 +291,7 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.agent_vel = h->d_agent_vel;
   L.agent_c = h->d_agent_c;
   L.agent_rest = h->d_agent_rest;
+  L.pin_rest = h->d_pin_rest;
   L.A = h->st_A;
   L.obstacles = h->d_obstacles;
   L.O = h->st_O;
@@ -664,6 +670,66 @@ void rest_forces(const sfw_params &p, const std::vector<std::pair<int32_t, int32
   }
 }
 
+// A person that can never move (desired_velocity == 0: lightsfm's speed clamp sets its velocity to 0 in every updatePosition)
+// next to a robot that stands still for the whole rollout (twist 0 at hand-over, sample (0, w): it may turn, its agent
+// velocity — the robot-LOCAL twist, ref :600-604 — and its position stay what they are) is at exact relative rest at EVERY
+// step, not only in the handed-over state: lightsfm's sign(theta) is the rounding noise of two atan2 there (0 for most
+// geometries, +-1 — a full-magnitude lateral term in Wr and Wp — for the others), the kernels' is 0.  The geometry
+// of such a pair is the same at every step of every such sample — robot at (rs.x, rs.y), person where it stands — so, like
+// rest_forces for the handed-over state, the host evaluates the reference's expression once per stage:
+//   out[0..1] = the robot position the table holds for (the kernels compare a step's robot record with it, bit for bit)
+//   out[2..3] = sum over the pinned people k of the LATERAL part of the force k exerts on the robot (joins the robot's social
+//               force of the step AFTER every step whose post-step robot record is that position at velocity 0)
+//   out[4+i]  = |force the robot exerts on person i| with the lateral part minus the same without it — what the kernels' Wp
+//               of person i lacks at every such step; 0 for a person that can move or that carries the robot's id (ref :692).
+// Returns false when no person is pinned (no table).  A robot that BRAKES to a stop during the rollout stands at a position
+// the device's own pose rollout produced; the rounding noise at that position is not reproduced.
+bool pinned_rest_table(const sfw_params &p, const sfw_robot_state &rs, const double *pos, const sfw_agent_const *cst, int A,
+                       double *out) {
+  bool any = false;
+  for (int i = 1; i < A; ++i) any |= (cst[i].desired_velocity == 0.0);
+  if (!any) return false;
+  out[0] = rs.x;
+  out[1] = rs.y;
+  out[2] = out[3] = 0.0;
+  for (int i = 0; i < A; ++i) out[4 + i] = 0.0;
+  // force exerted on `me` by `other`, both at velocity 0 (lightsfm computeSocialForce, one term):
+  // the whole term in (fx, fy), its angular part in (lx, ly)
+  auto pair_at_rest = [&](double mx, double my, double ox, double oy, double &fx, double &fy, double &lx, double &ly) {
+    fx = fy = lx = ly = 0.0;
+    const double dx = ox - mx, dy = oy - my;
+    const double dn = std::sqrt(dx * dx + dy * dy);
+    if (!(dn > 0.0)) return;
+    const double ux = dx / dn, uy = dy / dn;                  // diffDirection
+    const double ix = p.sfm_lambda * 0.0 + ux, iy = p.sfm_lambda * 0.0 + uy;  // interactionVector, velDiff = 0
+    const double il = std::sqrt(ix * ix + iy * iy);
+    if (!(il > 0.0)) return;
+    const double ex = ix / il, ey = iy / il;                  // interactionDirection
+    double theta = std::atan2(uy, ux) - std::atan2(ey, ex);   // angleTo, kept in (-pi, pi]
+    while (theta <= -M_PI) theta += 2.0 * M_PI;
+    while (theta > M_PI) theta -= 2.0 * M_PI;
+    const double B = p.sfm_gamma * il;
+    const double sv = p.sfm_n_prime * B * theta, sa = p.sfm_n * B * theta;
+    const double fv = -std::exp(-dn / B - sv * sv);
+    const double sg = theta > 0.0 ? 1.0 : theta < 0.0 ? -1.0 : 0.0;
+    const double fa = -sg * std::exp(-dn / B - sa * sa);
+    lx = p.sfm_force_factor_social * (fa * -ey);              // leftNormal = (-y, x)
+    ly = p.sfm_force_factor_social * (fa * ex);
+    fx = p.sfm_force_factor_social * (fv * ex + fa * -ey);
+    fy = p.sfm_force_factor_social * (fv * ey + fa * ex);
+  };
+  for (int i = 1; i < A; ++i) {
+    if (cst[i].desired_velocity != 0.0) continue;
+    double fx, fy, lx, ly;
+    pair_at_rest(rs.x, rs.y, pos[2 * i], pos[2 * i + 1], fx, fy, lx, ly);  // on the robot, by person i
+    out[2] += lx;
+    out[3] += ly;
+    pair_at_rest(pos[2 * i], pos[2 * i + 1], rs.x, rs.y, fx, fy, lx, ly);  // on person i, by the robot
+    if (cst[i].id != cst[0].id) out[4 + i] = std::sqrt(fx * fx + fy * fy) - std::sqrt((fx - lx) * (fx - lx) + (fy - ly) * (fy - ly));
+  }
+  return true;
+}
+
 // Everything of a stage that depends on sfw_params: the K1->K2 tables ([S][chunk] records, chunk bounded
 // by the table budget) and the shared-prefix plan (classes of the velocity sequences under dt = sim_time/S).
 // Run by every stage, and again by a launch when sfw_set_params came in between (the reference re-reads
@@ -727,7 +793,11 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     const size_t o_fp = 0, o_ag = o_fp + up16(sizeof(double) * (h->h_footprint.empty() ? 2 : h->h_footprint.size())),
                  o_lin = o_ag + up16(h->h_agents.size()), o_ang = o_lin + up16(sizeof(double) * nv),
                  o_rest = o_ang + up16(sizeof(double) * nw),
-                 total = o_rest + (rest ? up16(sizeof(double) * 2 * static_cast<size_t>(h->A)) : 0);
+                 o_pin = o_rest + (rest ? up16(sizeof(double) * 2 * static_cast<size_t>(h->A)) : 0),
+                 pin_doubles = 4 + static_cast<size_t>(h->A > 0 ? h->A : 0),
+                 // (room for the pinned-rest table whenever the robot stands still at hand-over: whether one is needed is known
+                 // once the agents' constants have been looked at, below)
+                 total = o_pin + ((h->pin_rest_on && rs->vx == 0.0 && rs->vy == 0.0 && h->A > 1) ? up16(sizeof(double) * pin_doubles) : 0);
     SFW_HIP(h, h->pin_world.reserve(total));
     SFW_HIP(h, h->world.reserve(total));
     char *pb = h->pin_world.p;
@@ -744,9 +814,22 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
       h->st_rest_pv.insert(h->st_rest_pv.end(), vel, vel + 2 * h->A);
       rest_forces(h->params, h->rest_pairs, pos, vel, h->A, reinterpret_cast<double *>(pb + o_rest));
     }
+    bool pinned = false;
+    if (total > o_pin)
+      pinned = pinned_rest_table(h->params, *rs, reinterpret_cast<const double *>(h->h_agents.data()),
+                                 reinterpret_cast<const sfw_agent_const *>(h->h_agents.data() + h->ao_cst), h->A,
+                                 reinterpret_cast<double *>(pb + o_pin));
     SFW_HIP(h, hipMemcpyAsync(h->world.p, pb, total, hipMemcpyHostToDevice, h->stream));
     SFW_HIP(h, h->pin_world.mark(h->stream));
     const char *db = h->world.p;
+    h->d_pin_rest = pinned ? reinterpret_cast<const double *>(db + o_pin) : nullptr;
+    h->st_pin_doubles = pinned ? pin_doubles : 0;
+    if (pinned) {
+      const double *pos = reinterpret_cast<const double *>(h->h_agents.data());
+      const sfw_agent_const *cst = reinterpret_cast<const sfw_agent_const *>(h->h_agents.data() + h->ao_cst);
+      h->st_pin_pos.assign(pos, pos + 2 * h->A);
+      h->st_pin_cst.assign(cst, cst + h->A);
+    }
     h->d_footprint = reinterpret_cast<const double *>(db + o_fp);
     h->d_agent_pos = reinterpret_cast<const double *>(db + o_ag);
     h->d_agent_vel = reinterpret_cast<const double *>(db + o_ag + h->ao_vel);
@@ -805,6 +888,14 @@ int launch_common(sfw_handle h) {
                   reinterpret_cast<double *>(h->pin_out.p));
       SFW_HIP(h, hipMemcpyAsync(const_cast<double *>(h->d_agent_rest), h->pin_out.p, bytes, hipMemcpyHostToDevice, h->stream));
       SFW_HIP(h, hipStreamSynchronize(h->stream));  // pin_out is the fetch buffer too: rare path, keep it simple
+    }
+    if (h->d_pin_rest && h->st_pin_doubles) {  // ... and so does the pinned-rest table
+      const size_t bytes = sizeof(double) * h->st_pin_doubles;
+      SFW_HIP(h, h->pin_cls.wait());
+      SFW_HIP(h, h->pin_out.reserve(bytes));
+      pinned_rest_table(h->params, h->rs, h->st_pin_pos.data(), h->st_pin_cst.data(), h->st_A, reinterpret_cast<double *>(h->pin_out.p));
+      SFW_HIP(h, hipMemcpyAsync(const_cast<double *>(h->d_pin_rest), h->pin_out.p, bytes, hipMemcpyHostToDevice, h->stream));
+      SFW_HIP(h, hipStreamSynchronize(h->stream));
     }
   }
   const int S = num_steps_of(h->params);
@@ -1011,6 +1102,7 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
     h->prefix_env.erase(std::unique(h->prefix_env.begin(), h->prefix_env.end()), h->prefix_env.end());
   }
   if (const char *b = std::getenv("SFW_FORCE_FLAT")) h->k2_form = std::atoi(b) == 1 ? SFW_K2_FLAT : std::atoi(b) == 0 ? SFW_K2_REGISTER : SFW_K2_AUTO;
+  if (const char *b = std::getenv("SFW_PIN_REST")) h->pin_rest_on = std::atoi(b) != 0;
   if (const char *b = std::getenv("SFW_TABLE_BUDGET_MB")) {
     long mb = std::atol(b);
     if (mb > 0) h->table_budget_bytes = static_cast<size_t>(mb) << 20;

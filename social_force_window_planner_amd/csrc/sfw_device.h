@@ -110,6 +110,10 @@ struct sfw_launch {
   const sfw_agent_const *agent_c;  // A
   const double *agent_rest;        // A x (fx, fy) or null: angular terms of the pairs at exact relative rest in the
                                    // handed-over state, evaluated on the host (sfw_capi.hip rest_forces)
+  const double *pin_rest;          // 4 + A doubles or null: a person that can never move next to a robot that stands still for
+                                   // the whole rollout is at exact relative rest at EVERY step; {robot x, y, lateral force on
+                                   // the robot (x, y), Wp per person or -1} evaluated on the host (sfw_capi.hip
+                                   // pinned_rest_table) for the steps whose robot record is (x, y) at velocity 0
   int32_t A;
   const double *obstacles;         // O x (x,y)
   int32_t O;

@@ -1118,6 +1118,20 @@ template <typename R, bool PIN_ALL> __device__ __forceinline__ sfm_consts<R> mak
   return k;
 }
 
+// A person that can never move next to a robot that stands still for the whole rollout (sfw_launch.pin_rest, built by
+// sfw_capi.hip pinned_rest_table; null in every launch without such a person): exact relative rest at every step, where the
+// pair loop's angular term is exactly 0 and lightsfm's the rounding noise of two atan2.  The host has evaluated the
+// reference's term for the one geometry such a pair can have.  It enters in a pass of its own behind the per-agent pass —
+// a wave-uniform branch no other launch takes, kept out of the loops whose register budgets are pinned
+// (tests/test_kernel_resources.py) — at a step whose post-step robot record is the table's position at velocity 0:
+//   * the robot's starting force of the NEXT step (its social force there is evaluated at this record) gets the lateral
+//     parts pin[2..3]; the pair pass adds the rest;
+//   * person i's social work gets pin[4 + i] = (the reference's Wp) - (the Wp the kernels have just counted: the same
+//     pair with the angular part 0), which is 0 for a person that can move.
+__device__ __forceinline__ bool pin_at_rest(const double *pin, const sfw_robot_step &rs) {
+  return rs.vx == 0.0 && rs.vy == 0.0 && rs.x == pin[0] && rs.y == pin[1];
+}
+
 // One agent slot after the pair pass of a step: integrate the person (the robot's
 // overwrite is the caller's), contact test, social-work terms, next step's
 // desired+obstacle force.  F = total force on the agent at the pre-step state
@@ -1623,6 +1637,20 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
           }
         }
     }
+    if (const double *const pin = late_args()->pin_rest) {  // (pin_at_rest: no launch of a BASELINE workload comes here)
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+        if (ok_[r] && lds_at<int>(smem, off::DEAD + g4_[r]) == 0 &&
+            pin_at_rest(pin, lds_at<sfw_robot_step>(smem, off::RSB + 8u * g4_[r]))) {
+          const int i = lds_at<int2>(smem, io_[r] + off::HG).y >> 1;
+          if (i == 0) {
+            fx[r] += pin[2];
+            fy[r] += pin[3];
+          } else {
+            sw[r] += pin[4 + i];
+          }
+        }
+    }
     __syncthreads();
     bool any_live = false;
     for (int g = 0; g < G; ++g) any_live |= (s.dead[g] == 0);
@@ -2106,6 +2134,17 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
         s.vx[0] = rs.vx;
         s.vy[0] = rs.vy;
       }
+    }
+    if (const double *const pin = La->pin_rest) {  // (pin_at_rest: no launch of a BASELINE workload comes here)
+      if (pin_at_rest(pin, rs))
+        for (int sl = lane_s; sl < A; sl += WAVE) {
+          if (sl == 0) {
+            s.fcx[0] += pin[2];
+            s.fcy[0] += pin[3];
+          } else {
+            s.swp[sl] += pin[4 + sl];
+          }
+        }
     }
     __syncthreads();
     if (s.dead[0] != 0) break;

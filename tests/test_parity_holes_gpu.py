@@ -555,12 +555,87 @@ def test_alignment_that_persists_past_the_handed_over_state(oracle_mod, hip_mod,
     assert np.max(np.abs(gc[v] - oc[v]) / np.abs(oc[v])) <= RTOL_NORTH_STAR and gb["index"] == ob["index"]
 
 
+def _noise_sign(mx, my, ox, oy):
+    """sign of lightsfm's theta for `me` at (mx, my) and `other` at (ox, oy), both at velocity 0: the difference of two atan2
+    of vectors equal up to rounding (the expression sequence of the oracle's sfm_pair; Python floats are IEEE doubles and
+    math.atan2 is this host's libm, which is what the oracle runs on)."""
+    dx, dy = ox - mx, oy - my
+    dn = math.sqrt(dx * dx + dy * dy)
+    ux, uy = dx / dn, dy / dn
+    il = math.sqrt(ux * ux + uy * uy)
+    th = math.atan2(uy, ux) - math.atan2(uy / il, ux / il)
+    return (th > 0) - (th < 0)
+
+
+@pytest.mark.parametrize("grid", ["cycle", "full"])
+def test_people_that_can_never_move_next_to_a_robot_that_stands_still(oracle_mod, hip_mod, monkeypatch, grid):
+    """a person with desired_velocity = 0 next to a robot whose twist is 0 — the samples of the linvel = 0 row: the
+    robot turns where it stands — is at exact relative rest with it at EVERY step.  lightsfm's sign(theta) is the rounding
+    noise of two atan2 there, +-1 for a few per cent of the geometries: a full-magnitude lateral term in Wr and Wp at every
+    step.  The people of this scene stand where that noise is not 0 (found with the oracle's own expression), the whole grid
+    INCLUDING the linvel = 0 row meets the oracle at 1e-9 in both organisations (a control cycle's 5 x 9 grid, and a 64 x 66
+    grid with its shared-prefix levels), and without the host-evaluated table (SFW_PIN_REST=0) the same row misses it."""
+    from social_force_window_planner_amd._abi import SFW_K2_FLAT, SFW_K2_REGISTER
+
+    nv, nw = (5, 9) if grid == "cycle" else (64, 66)
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=nv, nw=nw, n_people=12, seed=735, n_obstacles=(0 if grid == "full" else 24))
+    scene = syn.make_scene(w)
+    ag = scene.agents
+    rs = scene.robot_state
+    rs = (rs[0], rs[1], rs[2], 0.0, 0.0, 0.0)  # a stopped robot: its agent velocity (local twist) is (0, 0) too
+    ag[0].vx = ag[0].vy = 0.0
+    rng = np.random.default_rng(99)
+    pinned = (2, 5, 6, 8, 11)
+    found = {}
+    for i in pinned:  # a place 1.2 .. 2.5 m from the robot where the noise is not 0 for at least one direction of the pair
+        for _ in range(100000):
+            r, a = rng.uniform(1.2, 2.5), rng.uniform(-math.pi, math.pi)
+            x, y = rs[0] + r * math.cos(a), rs[1] + r * math.sin(a)
+            sg = (_noise_sign(rs[0], rs[1], x, y), _noise_sign(x, y, rs[0], rs[1]))
+            far = all(math.hypot(x - ag[j].x, y - ag[j].y) > 0.8 for j in range(1, len(ag)) if j != i)
+            if sg != (0, 0) and far:
+                found[i] = sg
+                break
+        assert i in found
+        ag[i].x, ag[i].y = x, y
+        if i != 8:
+            _stand(ag[i])  # (person 8 walks when handed over and is pinned by the clamp from the first step on)
+        ag[i].desired_velocity = 0.0
+    assert any(s[0] != 0 for s in found.values()) and any(s[1] != 0 for s in found.values()), found  # Wr and Wp both exercised
+    lin, ang = scene.linvels, scene.angvels
+    assert lin[0] == 0.0
+    o = oracle_mod.OracleScorer(default_params())
+    o.load_scene(scene)
+    oc, ob = o.score_grid(rs, lin, ang, scene.goal_args, n_threads=16)
+    row0 = slice(0, nw)
+    assert (oc[row0] >= 0).sum() >= 4
+    for form in (SFW_K2_FLAT, SFW_K2_REGISTER):
+        g = hip_mod.HipScorer(default_params())
+        g.set_k2_form(form)
+        g.load_scene(scene)
+        gc, gb = g.score_grid(rs, lin, ang, scene.goal_args)
+        _assert_parity(oc, ob, gc, gb, RTOL_F64)
+        if grid == "full":
+            assert g.plan_info()["levels"] > 0  # the stopped row ran through the shared-prefix tree
+    # the control: without the table the linvel = 0 row — and only it — misses the oracle
+    monkeypatch.setenv("SFW_PIN_REST", "0")
+    g = hip_mod.HipScorer(default_params())
+    g.load_scene(scene)
+    gc, _ = g.score_grid(rs, lin, ang, scene.goal_args)
+    v = oc >= 0
+    rel = np.where(v, np.abs(gc - oc) / np.maximum(np.abs(oc), 1e-300), 0.0)
+    assert rel[row0].max() > 1e-6, rel[row0].max()
+    assert rel[nw:].max() <= RTOL_F64
+
+
 def test_people_that_can_never_move(oracle_mod, hip_mod):
     """desired_velocity = 0 (the reference's people_velocity_ = 0, sensor_interface.cpp:503): accepted, and such people stay
     where they stand (the speed clamp of updatePosition).  Rows with linvel > 0 — the robot keeps a non-zero twist, so no
-    pair that enters the social work is ever at exact relative rest — match the oracle like any other scene.  (A STOPPED
-    robot next to such a person is at relative rest with it at every step: there lightsfm's sign(theta) is the rounding
-    noise of two atan2 — 0 for 96 % of the geometries, else +-1 — and the kernels' is 0: DESIGN.md §5.)"""
+    pair that enters the social work is ever at exact relative rest — match the oracle like any other scene.  (The linvel = 0
+    row of a robot that is still MOVING brakes to a stop during the rollout and is at relative rest with such a person from
+    there on, at a position the device's own pose rollout produced: lightsfm's sign(theta) is the rounding noise of two atan2
+    there — 0 for 96 % of the geometries, else +-1 — and the kernels' is 0, DESIGN.md §5.  A robot that stands still from
+    the start is the test above.)"""
     w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=9, nw=9, n_people=14, seed=733)
     scene = syn.make_scene(w)
     ag = scene.agents
