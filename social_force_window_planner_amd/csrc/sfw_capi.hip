@@ -118,6 +118,8 @@ struct sfw_planner_s {
   std::vector<std::pair<int32_t, int32_t>> rest_pairs;
   const double *d_agent_rest = nullptr;  // A x (fx, fy) in `world`, or null when there is no such pair
   const double *d_pin_rest = nullptr;  // see pinned_rest_table: the stage's table on the device, or null
+  int obs_tasks_force = -1;            // SFW_OBS_TASKS=0|1 in the environment of sfw_create: the flat form's laser-point pass as
+                                       // one lane per agent / as (agent, segment) tasks, whatever sfw_derive prices (tuning aid)
   bool pin_rest_on = true;             // SFW_PIN_REST=0 in the environment of sfw_create: no such table (tests: what it changes)
   size_t st_pin_doubles = 0;           // its length (4 + A) when the last stage built one
   std::vector<double> st_pin_pos;      // ... and what it was built from (sfw_set_params between stage and launch rebuilds it)
@@ -303,6 +305,7 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.n_cu = h->n_cu;
   L.n_xcd = h->n_xcd;
   sfw_derive(L);
+  if (h->obs_tasks_force >= 0 && L.O > 0) L.k.obs_tasks = h->obs_tasks_force;
   L.pair_tab = h->pair_tab.p;
   L.status = h->status.p;
   L.base_cost = h->base_cost.p;
@@ -1103,6 +1106,7 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
   }
   if (const char *b = std::getenv("SFW_FORCE_FLAT")) h->k2_form = std::atoi(b) == 1 ? SFW_K2_FLAT : std::atoi(b) == 0 ? SFW_K2_REGISTER : SFW_K2_AUTO;
   if (const char *b = std::getenv("SFW_PIN_REST")) h->pin_rest_on = std::atoi(b) != 0;
+  if (const char *b = std::getenv("SFW_OBS_TASKS")) h->obs_tasks_force = std::atoi(b) != 0 ? 1 : 0;
   if (const char *b = std::getenv("SFW_TABLE_BUDGET_MB")) {
     long mb = std::atol(b);
     if (mb > 0) h->table_budget_bytes = static_cast<size_t>(mb) << 20;
