@@ -2073,17 +2073,24 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
               default: obstacle_segment_multi_uniform<R, KA>(k, pts, c.O, Lseg, seg, pxj, pyj, nis, axj, ayj); break;
             }
           };
+#if !defined(SFW_ABL_NOOBSLOOP)  // (ablation builds: time only, results wrong by construction)
           if (in_lds) {
             if (SFW_OBS_UNIFORM_LDS) run_uniform(pts_l);
             else run(pts_l);
           } else if (SFW_OBS_UNIFORM) run_uniform(pts_g);
           else run(pts_g);
+#endif
           // The sixteen segment sums of an agent are added in segment order by one lane per component: two of the lanes'
           // agent slots at a time go through LDS (2 KB: what the wave can spare without losing a wave per SIMD at the target
           // crowd), lane l < 16 sums component l & 1 of agent slot j0 + (l >> 1 & 1) of lane group l >> 2.
 #pragma unroll
           for (int j0 = 0; j0 < KA; j0 += 2) {
+#if defined(SFW_ABL_NOREDUCE)
+            asm volatile("" :: "v"(axj[j0]), "v"(ayj[j0]), "v"(axj[j0 + 1]), "v"(ayj[j0 + 1]));
+            if (false) {
+#else
             if (j0 < nj) {
+#endif
               s.opart[lane] = double2{static_cast<double>(axj[j0]), static_cast<double>(ayj[j0])};
               s.opart[WAVE + lane] = double2{static_cast<double>(axj[j0 + 1]), static_cast<double>(ayj[j0 + 1])};
               __syncthreads();

@@ -578,6 +578,8 @@ def test_people_that_can_never_move_next_to_a_robot_that_stands_still(oracle_mod
     from social_force_window_planner_amd._abi import SFW_K2_FLAT, SFW_K2_REGISTER
 
     nv, nw = (5, 9) if grid == "cycle" else (64, 66)
+    if grid == "full":
+        monkeypatch.setenv("SFW_PREFIX", "4,9")  # two shared-prefix levels whatever the planner would choose for a stopped robot
     w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=nv, nw=nw, n_people=12, seed=735, n_obstacles=(0 if grid == "full" else 24))
     scene = syn.make_scene(w)
     ag = scene.agents
