@@ -626,11 +626,10 @@ __device__ __forceinline__ void desired_force(const agent_consts &k, double px, 
 //
 // Summation order (the same in both kernel organisations, so that they stay bit-identical): the points are cut
 // into OBS_SEG = 16 consecutive segments of L = ceil(O / 16) points; a segment's terms are added in point order
-// starting from 0, the segment sums are added in segment order.  The register-resident form runs the segments
-// one after the other on the agent's lane (every lane owns an agent there); the flat form makes every (agent, segment)
-// pair a task and walks the tasks 256 at a time — 16 agents x 16 segments per round, four agents per lane — whatever the
-// crowd size: with 51 agents a lane evaluates 3 x 4 + 1 agents on its 45 points of a 720-point scan = 585 evaluations where
-// one lane per agent ran 720 on 51 of the 64 lanes (round 3's form above 48 agents; 8 segments until round 3).
+// starting from 0, the segment sums are added in segment order.  (Round 5 measured a two-level order — groups of four segments,
+// then the groups: a chain of seven dependent additions instead of sixteen — and took it back out: the lanes' reduction gained
+// ~80 cycles per phase, the register form's and the lane-per-agent pass's nested segment loops lost 14-22 us per 40-step control
+// cycle with 50 people, profiles/r05_cycle_k2.txt.)
 constexpr int OBS_SEG = 16;
 constexpr int OBS_AGENT_LANES = WAVE / OBS_SEG;  // flat form: 4 lanes per segment, each with its own agents
 #ifndef SFW_OBS_KA
@@ -922,6 +921,16 @@ __device__ __forceinline__ void obstacle_sums(const sfm_consts<R> &k, const agen
   scale = obstacle_scale<R>(k, c, radius);
 }
 
+// The value of the neighbouring lane (lane ^ 1), as a DPP quad permutation: two vector instructions where __shfl_xor goes
+// through the LDS crossbar (ds_bpermute_b32 x 2: ~130 cycles on the chain of a wave with the GPU to itself)
+__device__ __forceinline__ double swap_pair(double v) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  constexpr int QP_1032 = 0xB1;  // quad_perm:[1,0,3,2]
+  const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(u)), QP_1032, 0xf, 0xf, true));
+  const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(u >> 32)), QP_1032, 0xf, 0xf, true));
+  return __builtin_bit_cast(double, (static_cast<uint64_t>(hi) << 32) | lo);
+}
+
 // LDS map of one wave.  Agent state lives in PLANES of `cap` doubles each — px, py, vx, vy, the force
 // accumulators fjx, fjy (received "as j") and, in the flat kernel, fcx, fcy (received "as i") — `cap` doubles
 // apart, so (1) a wave's ds_read_b64 / ds_add_f64 of consecutive agents hit consecutive 8-byte words (all 32
@@ -942,7 +951,8 @@ struct lds_layout {
   sfw_agent_const *ac;  // the per-agent launch constants as they sit in global memory (48 B records: one address
                         // register per agent reaches every field through the DS offset field)
   double *swp;
-  double2 *opart;       // flat form with laser points: the 64 lanes' segment sums of two of their agents ([2][64])
+  double2 *opart;       // flat form with laser points: the 64 lanes' segment sums of two of their agents ([2][64]; of all four
+                        // — [4][64] — in the launches that leave the GPU under-filled, obs_in_lds: LDS is plentiful there)
   double *wr;           // flat form with laser points: the robot's social-work term waiting for its obstacle part [0] and
                         // the two components of that part [1], [2]
   double *oscale;       // flat form with laser points: obstacle_scale of every agent, formed once per launch (the reduction
@@ -978,7 +988,7 @@ struct lds_layout {
       fcy = reinterpret_cast<double *>(take(plane));
       rsb = reinterpret_cast<sfw_robot_step *>(take(sizeof(sfw_robot_step) * 2));
       swp = reinterpret_cast<double *>(take(sizeof(double) * GA));
-      opart = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? 2 * 64 : 0)));
+      opart = reinterpret_cast<double2 *>(take(sizeof(double2) * (O > 0 ? (obs_in_lds ? 4 : 2) * 64 : 0)));
       wr = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? 4 : 0)));
       oscale = reinterpret_cast<double *>(take(sizeof(double) * (O > 0 ? A : 0)));
       obs = reinterpret_cast<double2 *>(take(sizeof(double2) * (obs_in_lds ? O + 2 : 0)));  // + 2: read ahead, never evaluated
@@ -2080,44 +2090,53 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
           } else if (SFW_OBS_UNIFORM) run_uniform(pts_g);
           else run(pts_g);
 #endif
-          // The sixteen segment sums of an agent are added in segment order by one lane per component: two of the lanes'
-          // agent slots at a time go through LDS (2 KB: what the wave can spare without losing a wave per SIMD at the target
-          // crowd), lane l < 16 sums component l & 1 of agent slot j0 + (l >> 1 & 1) of lane group l >> 2.
+          // The sixteen segment sums of an agent slot are added in segment order by one lane per (slot, component) out of LDS.  SL slots go through LDS at a time: two in a GPU-filling launch
+          // (2 KB: what the wave can spare without losing a wave per SIMD at the target crowd), all four in a launch that leaves
+          // the GPU under-filled (the ones that also keep the points in LDS) when the round has more than two — there a phase is
+          // a latency chain (write, wait, sixteen loads, sixteen additions, the agent's update: 570 cycles, a seventh of such a
+          // wave's step, profiles/r05_cycle_ablation.txt) and one phase does where two did.  Lane l < 8 SL: component l & 1 of agent slot
+          // j0 + (l >> 1) % SL of lane group l / (2 SL).
+          auto reduce = [&](auto sl_tag) {
+            constexpr int SL = decltype(sl_tag)::value;
 #pragma unroll
-          for (int j0 = 0; j0 < KA; j0 += 2) {
+            for (int j0 = 0; j0 < KA; j0 += SL) {
 #if defined(SFW_ABL_NOREDUCE)
-            asm volatile("" :: "v"(axj[j0]), "v"(ayj[j0]), "v"(axj[j0 + 1]), "v"(ayj[j0 + 1]));
-            if (false) {
+              asm volatile("" :: "v"(axj[j0]), "v"(ayj[j0]), "v"(axj[j0 + 1]), "v"(ayj[j0 + 1]));
+              if (false) {
 #else
-            if (j0 < nj) {
+              if (j0 < nj) {
 #endif
-              s.opart[lane] = double2{static_cast<double>(axj[j0]), static_cast<double>(ayj[j0])};
-              s.opart[WAVE + lane] = double2{static_cast<double>(axj[j0 + 1]), static_cast<double>(ayj[j0 + 1])};
-              __syncthreads();
-              const int comp = lane & 1, js = (lane >> 1) & 1, gsub = lane >> 2;  // gsub < 4 for lane < 16
-              const int a = a0 + gsub + OBS_AGENT_LANES * (j0 + js);
-              if (lane < 16 && a < A) {
-                const double *const col = part + 2 * (WAVE * js + gsub) + comp;  // segment q of that agent: + 2 * 4 * q
-                // all sixteen loads first, then the additions in segment order (left to the compiler: load two, wait, add two,
-                // eight LDS round trips one after the other — 850 cycles of a lone wave's step per phase)
-                double v[OBS_SEG];
 #pragma unroll
-                for (int q = 0; q < OBS_SEG; ++q) v[q] = col[2 * OBS_AGENT_LANES * q];
-                double *const acc = (comp == 0 ? s.fcx : s.fcy) + a;  // (the robot's: not used)
-                const double sc = s.oscale[a], acc0 = *acc, wr0 = s.wr[0];
-                asm volatile("" ::: "memory");
-                R t = R(0);  // + 0 first, as obstacle_sums does; empty segments of a short scan add +0
+                for (int u = 0; u < SL; ++u)
+                  s.opart[u * WAVE + lane] = double2{static_cast<double>(axj[j0 + u]), static_cast<double>(ayj[j0 + u])};
+                __syncthreads();
+                const int comp = lane & 1, js = (lane >> 1) & (SL - 1), gsub = lane / (2 * SL);  // gsub < 4 for lane < 8 SL
+                const int a = a0 + gsub + OBS_AGENT_LANES * (j0 + js);
+                if (lane < 8 * SL && a < A) {
+                  const double *const col = part + 2 * (WAVE * js + gsub) + comp;  // segment q of that agent: + 2 * 4 * q
+                  // all sixteen loads first, then the additions (left to the compiler: load two, wait, add two, eight LDS
+                  // round trips one after the other)
+                  double v[OBS_SEG];
 #pragma unroll
-                for (int q = 0; q < OBS_SEG; ++q) t += static_cast<R>(v[q]);
-                const double f = static_cast<double>(t) * sc;
-                // the robot's Wr needs both components: lane 1 (y) hands its to lane 0 (x) — a lane swap inside the quad, no LDS
-                const double f_other = __shfl_xor(f, 1, WAVE);
-                if (a != 0) *acc = fma(static_cast<double>(t), sc, acc0);
-                else if (comp == 0) s.swp[0] += wr0 + fast_norm(f, f_other);
+                  for (int q = 0; q < OBS_SEG; ++q) v[q] = col[2 * OBS_AGENT_LANES * q];
+                  double *const acc = (comp == 0 ? s.fcx : s.fcy) + a;  // (the robot's: not used)
+                  const double sc = s.oscale[a], acc0 = *acc, wr0 = s.wr[0];
+                  asm volatile("" ::: "memory");
+                  R t = R(0);  // + 0 first, as obstacle_sums does; empty segments of a short scan add +0
+#pragma unroll
+                  for (int q = 0; q < OBS_SEG; ++q) t += static_cast<R>(v[q]);
+                  const double f = static_cast<double>(t) * sc;
+                  // the robot's Wr needs both components: lane 1 (y) hands its to lane 0 (x) — a swap inside the quad
+                  const double f_other = swap_pair(f);
+                  if (a != 0) *acc = fma(static_cast<double>(t), sc, acc0);
+                  else if (comp == 0) s.swp[0] += wr0 + fast_norm(f, f_other);
+                }
+                __syncthreads();
               }
-              __syncthreads();
             }
-          }
+          };
+          if (in_lds && nj > 2) reduce(std::integral_constant<int, (KA >= 4 ? 4 : 2)>{});
+          else reduce(std::integral_constant<int, 2>{});
         }
       } else {
         // A short scan: the agent's lane runs the sixteen segments itself, the points through the scalar cache (the rounds
