@@ -273,8 +273,11 @@ typedef struct sfw_plan_info {
                            the same number of those (0: none).  Costs do not depend on it.                      */
 } sfw_plan_info;
 int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out);
-/* The plan a single-chunk stage of this grid would choose, computed on the
- * host alone (no handle, no device): end steps of the levels and their class
+/* The plan a single-chunk stage of this grid would choose ON A WHOLE MI355X
+ * (256 compute units; SFW_DEVICE_CUS in the environment pretends another
+ * count, as it does for a handle — a handle on a partition reads its own
+ * device and may plan differently: sfw_grid_plan_info says what it chose),
+ * computed on the host alone (no handle, no device): end steps of the levels and their class
  * counts (row classes x column classes), up to cap entries; *n_levels = 0
  * when sharing does not pay (fewer than 4096 samples, fewer than two agents,
  * or nothing to share).  vx0 / vtheta0: the robot's current velocities,

@@ -1118,7 +1118,14 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
     h->n_cu = env_device_cus(h->n_cu);
-    h->n_xcd = std::max(1, h->n_cu / SFW_CUS_PER_XCD);
+    // XCDs: what the device says (hipDeviceAttributeNumberOfXccs; 8 on a whole MI355X, 1 on a CPX partition) unless the CU count
+    // is pretended (SFW_DEVICE_CUS) or the attribute is not answered — then CUs / 32, right for gfx950's 32-CU XCDs only
+    int xccs = 0;
+    if (!std::getenv("SFW_DEVICE_CUS") && hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, device) == hipSuccess && xccs >= 1)
+      h->n_xcd = xccs;
+    else
+      h->n_xcd = std::max(1, h->n_cu / SFW_CUS_PER_XCD);
+    (void)hipGetLastError();  // (an unanswered attribute is not an error of this call)
     if (const char *b = std::getenv("SFW_DEVICE_XCDS")) {
       const long v = std::atol(b);
       if (v >= 1 && v <= 64) h->n_xcd = static_cast<int>(v);

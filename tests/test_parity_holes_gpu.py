@@ -619,6 +619,35 @@ def test_people_that_can_never_move_next_to_a_robot_that_stands_still(oracle_mod
         _assert_parity(oc, ob, gc, gb, RTOL_F64)
         if grid == "full":
             assert g.plan_info()["levels"] > 0  # the stopped row ran through the shared-prefix tree
+    if grid == "cycle":
+        # the same through the other entry points: two ranks of one process (rank 0 holds the linvel = 0 row; every rank builds
+        # its own table in its stage), the scalar call sites' sfw_score_one, and a stage whose lightsfm parameters change
+        # before the launch (the table depends on them: rebuilt by the launch)
+        from social_force_window_planner_amd._abi import SFW_MULTI_HOST_REDUCE
+
+        m = hip_mod.MultiScorer(default_params(), devices=(0, 0), exchange=SFW_MULTI_HOST_REDUCE)
+        m.load_scene(scene)
+        mc, mb = m.score_grid(rs, lin, ang, scene.goal_args)
+        assert np.array_equal(mc, gc) and mb == gb
+        m.close()
+        for iw in (1, 4):
+            c1, _ = g.score_one(rs, 0.0, 0.0, float(ang[iw]), scene.goal_args)
+            o1, _ = o.score_one(rs, 0.0, 0.0, float(ang[iw]), scene.goal_args)
+            assert o1 >= 0 and abs(c1 - o1) <= RTOL_F64 * abs(o1), (iw, c1, o1)
+        p2 = default_params()
+        p2.sfm_force_factor_social, p2.sfm_gamma = 3.3, 0.5
+        g2 = hip_mod.HipScorer(default_params())
+        g2.load_scene(scene)
+        g2.stage(rs, lin, ang, scene.goal_args)
+        g2.set_params(p2)
+        g2.launch()
+        c2 = g2.fetch(want_costs=True)[0]
+        o2 = oracle_mod.OracleScorer(p2)
+        o2.load_scene(scene)
+        oc2, _ = o2.score_grid(rs, lin, ang, scene.goal_args, n_threads=16)
+        assert np.array_equal(oc2 < 0, c2 < 0)
+        v2 = oc2 >= 0
+        assert v2[row0].any() and np.max(np.abs(c2[v2] - oc2[v2]) / np.abs(oc2[v2])) <= RTOL_F64
     # the control: without the table the linvel = 0 row — and only it — misses the oracle
     monkeypatch.setenv("SFW_PIN_REST", "0")
     g = hip_mod.HipScorer(default_params())
