@@ -1756,6 +1756,9 @@ __device__ __forceinline__ void wait_pair_entries(uint32_t &io, uint32_t &jo) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(io), "+v"(jo));
 }
 
+#ifndef SFW_FIRST_PAIRS_IN_REGS
+#define SFW_FIRST_PAIRS_IN_REGS 1  // flat form: the first 64 pairs' table entries stay in registers across the rollout
+#endif
 #ifndef SFW_FLAT_WAVES
 #define SFW_FLAT_WAVES 5  // waves per SIMD the flat kernel is compiled for (<= 96 VGPRs; tuning knob, csrc/Makefile EXTRA)
 #endif
@@ -1894,6 +1897,16 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
     }
   };
   if (step_begin < step_end) fetch_robot(L.rstep, L.rstep_stride, step_begin, step_begin & 1);
+  // (the 64-double planes only — crowds of up to 63 agents, every control cycle —: the larger capacities' kernels have no
+  // registers to spare, tests/test_kernel_resources.py)
+  constexpr bool FIRST_IN_REGS = SFW_FIRST_PAIRS_IN_REGS && CAP == 64;
+  uint32_t i0 = 0, j0 = 0;  // the first iteration's pair-table entries (see the pair loop)
+  if constexpr (FIRST_IN_REGS) {
+    if (n_it > 0) {
+      load_pair_entries(tab_i, tab_j, lane_off, i0, j0);
+      wait_pair_entries(i0, j0);
+    }
+  }
 
 #if defined(SFW_ABL_HALF_LDS)
   double abl_ix = s.px[lane < A ? lane : 0], abl_iy = s.py[lane < A ? lane : 0], abl_fx = 0.0, abl_fy = 0.0;
@@ -1955,6 +1968,33 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
       k.c_vel = sfwm::vgpr_copy_here(s_cvel);
       k.c_ang = sfwm::vgpr_copy_here(s_cang);
     }
+    if constexpr (FIRST_IN_REGS) {
+    if (n_it > 0) {
+      // The first 64 pairs' table entries stay in registers for the whole rollout (i0, j0: loaded in front of it): a wave with
+      // the GPU to itself — a control cycle's, a coarse shared-prefix level's — otherwise opens every step with a round trip
+      // to the L1 that nothing hides (crowds of up to 11 agents have no other pairs).
+      uint32_t ia, ja, ib, jb;
+      const uint16_t *ti = tab_i + WAVE, *tj = tab_j + WAVE;  // the second iteration's entries
+      int left = n_it - 1;  // iterations after the first: a plain scalar countdown
+      if (left >= 1) load_pair_entries(ti, tj, lane_off, ia, ja);
+      pair_at(k, i0, j0);
+      ti += WAVE;
+      tj += WAVE;
+      for (; left >= 2; left -= 2, ti += 2 * WAVE, tj += 2 * WAVE) {
+        wait_pair_entries(ia, ja);  // also covers the robot record issued a step ago
+        load_pair_entries(ti, tj, lane_off, ib, jb);
+        pair_at(k, ia, ja);
+        wait_pair_entries(ib, jb);
+        if (left > 2) load_pair_entries(ti + WAVE, tj + WAVE, lane_off, ia, ja);
+        pair_at(k, ib, jb);
+      }
+      if (left == 1) {
+        wait_pair_entries(ia, ja);
+        pair_at(k, ia, ja);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the robot record issued a step ago (landed long since)
+    } else {
     if (n_it > 0) {
       uint32_t ia, ja, ib, jb;
       load_pair_entries(tab_i, tab_j, lane_off, ia, ja);
@@ -1974,6 +2014,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
       }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     }
     __syncthreads();
 #if defined(SFW_ABL_HALF_LDS)
