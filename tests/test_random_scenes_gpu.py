@@ -94,7 +94,10 @@ def oracle_sensitivity(oracle_mod, scene, p, rs, ga, lin, ang, base, eps=2e-14, 
 # seeds of three — by the north star's 1e-4 whatever the oracle's response is.  Seeds with steps of at most 0.05 s get no
 # allowance.  The seeds that took the allowance are collected; the 40 seeds of this test need it for none (round 4: none
 # either; the 3000-seed sweeps find ~1 % of the scenes in that regime, profiles/r05_parity_sweep.txt).
-CHAOS_FACTOR = 50.0
+# (CHAOS_FACTOR: 50 in round 4, with the degree-8 exponential; the degree-9 build's largest ratio over the 6000 scenes of the two
+# sweeps is 15.5, the next 4.6, every other below 2.3 — the oracle's response is measured with three random probes, a noisy lower
+# bound of its conditioning)
+CHAOS_FACTOR = 20.0
 CHAOS_SEEDS_MAX = 0
 WELL_CONDITIONED_GRAN = 0.05
 NORTH_STAR_REL = 1e-4
