@@ -63,12 +63,13 @@ typedef enum sfw_status {
                                threshold stay double; only the pair/obstacle
                                FORCES are evaluated in float  */
 #define SFW_PRECISION_F64_STRICT 2 /* everything in double as SFW_PRECISION_F64,
-                               with the polynomials of the pair term one degree
-                               longer each (asin 8 / exp 9: that term at ~1e-14
-                               relative instead of ~1e-12; K2 +2.5 %).  For the
-                               caller who wants the last digits of the parity
-                               margin back (what the two buy on
-                               the 3000-scene sweeps)                         */
+                               with the angle's polynomial one degree longer
+                               (asin 8 / exp 9 against the default's 7 / 9 —
+                               7 / 8 until round 4 —: the pair term at ~1e-14
+                               relative instead of ~5e-14; K2 +1 %).  Kept for
+                               callers that selected it; since the default
+                               evaluates the exponential at degree 9 the two
+                               are within a digit of each other */
 
 /*
  * Scoring parameters = the subset of ControllerParams

@@ -1,5 +1,6 @@
-// sfw_kernels_strict.hip — the K2 kernels once more, with the polynomial degrees of round 2 (asin 8 / exp 9: the pair term at
-// ~1e-14 relative instead of ~1e-12), for SFW_PRECISION_F64_STRICT.  Same source, compiled a second time: the degrees are
+// sfw_kernels_strict.hip — the K2 kernels once more, with the polynomial degrees of round 2 (asin 8 / exp 9), for
+// SFW_PRECISION_F64_STRICT.  Since round 5 the default build evaluates the exponential at degree 9 too (asin 7 / exp 9), so
+// this build differs by one degree of the angle's polynomial only.  Same source, compiled a second time: the degrees are
 // compile-time constants of the Horner chains (an issue slot each), so the choice between the two is a choice between two
 // sets of kernels, made per launch by sfw_capi.hip.  Every external symbol of sfw_kernels.hip is renamed for this
 // translation unit; only sfw_launch_social_strict is used (the pose rollout, the footprint check and the selection do not
