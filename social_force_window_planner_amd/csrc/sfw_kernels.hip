@@ -2383,7 +2383,10 @@ static wave_plan plan_for(int A, int64_t T, int O, int form, int cus) {
   }
   // ... and a robot alone among laser points: the flat form spreads the points' sixteen segments over sixteen lanes
   // (the item thresholds were measured on 256 compute units and scale with the device: 6 / 12 / 16 items per CU)
-  if (T <= static_cast<int64_t>(A <= 8 ? 6 : A <= 12 ? 12 : 16) * cus && (A >= 2 || O > 0)) best = flat;
+#ifndef SFW_FLAT_ITEMS_PER_CU
+#define SFW_FLAT_ITEMS_PER_CU 16
+#endif
+  if (T <= static_cast<int64_t>(A <= 8 ? 6 : A <= 12 ? 12 : SFW_FLAT_ITEMS_PER_CU) * cus && (A >= 2 || O > 0)) best = flat;
   if (form == SFW_K2_FLAT && (A >= 2 || O > 0)) best = flat;
   if (form == SFW_K2_REGISTER && A <= 2 * WAVE) best = reg;
   return best;
