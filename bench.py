@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument("--inproc-workload", default="cfg5",
                     help="N > 1: the workload rank 0 also scores through sfw_multi_score_grid over all N devices (extra.inproc_multi_*)")
     ap.add_argument("--inproc-child", default=None, help=argparse.SUPPRESS)  # workload:devices:exchange:steps:warmup
-    ap.add_argument("--inproc-timeout", type=float, default=420.0,
+    ap.add_argument("--inproc-timeout", type=float, default=180.0,
                     help="N > 1: wall-clock limit of each one-process multi-device measurement (run in a child process)")
     ap.add_argument("--grid", default=None, help="override the sample grid, e.g. 512x512 (experiments only)")
     ap.add_argument("--verify", action="store_true", help=argparse.SUPPRESS)  # the default since round 4 (kept for old command lines)
