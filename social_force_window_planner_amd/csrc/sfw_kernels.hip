@@ -142,10 +142,14 @@ __device__ double footprint_cost(const sfw_launch &L, double x, double y, double
   return static_cast<double>(fc);  // >= 254 (lethal / unknown on an edge): illegal, like the reference's -1 / -2
 }
 
-// reference sfw_planner.hpp:457-463
+// reference sfw_planner.hpp:457-463: if ((vg - vi) >= 0) return min(vg, vi + a_max dt); return max(vg, vi - a_max dt);
+// Both candidates and a select instead of the branch: the recurrence is the serial chain at the head of every launch (one
+// lane walks S steps), and a divergent branch costs such a lane ~100 cycles per step where the select costs two
+// instructions (profiles/r05_k1small_ablation.txt).  Same operations on the same values: bit-identical.
 __device__ __forceinline__ double new_velocity(double vg, double vi, double a_max, double dt) {
-  if ((vg - vi) >= 0) return fmin(vg, vi + a_max * dt);
-  return fmax(vg, vi - a_max * dt);
+  const double step = a_max * dt;
+  const double up = fmin(vg, vi + step), dn = fmax(vg, vi - step);
+  return (vg - vi) >= 0 ? up : dn;
 }
 // reference sfw_planner.hpp:399-407 (float in, float out)
 __device__ __forceinline__ float normalize_angle_f(float val, float mn, float mx) {
@@ -317,6 +321,7 @@ __global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const
   __shared__ double2 cs[K1_SMALL_MAX_STEPS], dxy[K1_SMALL_MAX_STEPS];
   __shared__ double xs[K1_SMALL_MAX_STEPS + 1], ys[K1_SMALL_MAX_STEPS + 1];
   __shared__ int code[K1_SMALL_MAX_STEPS];
+  __shared__ double quot[K1_SMALL_MAX_STEPS];  // code / 255.0 of every step (ref :575), formed across the lanes
   __shared__ double th_end;
   const int64_t local = blockIdx.x;
   const int64_t t = L.chunk_begin + local;
@@ -326,7 +331,8 @@ __global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const
   const bool scored = !(L.skip_zero_sample && vx_samp == 0.0 && vth_samp == 0.0);
   const double dt = L.dt;
   const int tid = threadIdx.x;
-  // (1) velocities and headings
+  // (1) velocities and headings: lanes 0, 1, 2 walk ONE loop, each with its own target, velocity and limit (as three
+  // branches of an if the wave ran the three recurrences one after the other); lane 2 also sums the heading
   if (tid == 0) {
     if (!scored) {
       L.status[t] = SFW_ST_SKIPPED;
@@ -335,19 +341,20 @@ __global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const
       L.status[t] = SFW_ST_VALID;  // the costmap scan downgrades it if a step is illegal
     }
     if (L.coll_step) L.coll_step[t] = -1;
-    double v = L.rs.vx;
-    for (int i = 0; i < S; ++i) vxs[i] = v = new_velocity(vx_samp, v, L.ga.acc_x, dt);   // ref :581
-  } else if (tid == 1) {
-    double v = L.rs.vy;
-    for (int i = 0; i < S; ++i) vys[i] = v = new_velocity(vy_samp, v, L.ga.acc_y, dt);   // ref :582
-  } else if (tid == 2) {
-    double v = L.rs.vtheta, th_i = L.rs.theta;
+  }
+  if (tid < 3) {
+    const double target = tid == 0 ? vx_samp : tid == 1 ? vy_samp : vth_samp;      // ref :581-583
+    const double a_max = tid == 0 ? L.ga.acc_x : tid == 1 ? L.ga.acc_y : L.ga.acc_theta;
+    double v = tid == 0 ? L.rs.vx : tid == 1 ? L.rs.vy : L.rs.vtheta;
+    double th_i = L.rs.theta;
+    double *const out = tid == 0 ? vxs : tid == 1 ? vys : th;
     for (int i = 0; i < S; ++i) {
-      v = new_velocity(vth_samp, v, L.ga.acc_theta, dt);                                // ref :583
-      th[i] = th_i;  // heading before this step's update: ref :586-588 integrate with the old theta
-      th_i = th_i + v * dt;
+      v = new_velocity(target, v, a_max, dt);
+      // lanes 0, 1: the new velocity; lane 2: the heading BEFORE this step's update (ref :586-588 integrate with the old theta)
+      out[i] = tid == 2 ? th_i : v;
+      th_i = th_i + v * dt;  // (meaningful on lane 2 only)
     }
-    th_end = th_i;
+    if (tid == 2) th_end = th_i;
   }
   __syncthreads();
   // (2) sines and position increments, one step per lane
@@ -361,14 +368,13 @@ __global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const
   }
   __syncthreads();
   // (3) positions: xs[i] = pose before step i, xs[S] = final pose
-  if (tid == 0) {
-    double x = L.rs.x;
-    xs[0] = x;
-    for (int i = 0; i < S; ++i) xs[i + 1] = x = x + dxy[i].x;
-  } else if (tid == 1) {
-    double y = L.rs.y;
-    ys[0] = y;
-    for (int i = 0; i < S; ++i) ys[i + 1] = y = y + dxy[i].y;
+  // (lanes 0 and 1 in ONE loop, as above)
+  if (tid < 2) {
+    double p = tid == 0 ? L.rs.x : L.rs.y;
+    double *const out = tid == 0 ? xs : ys;
+    const double *const inc = reinterpret_cast<const double *>(dxy) + tid;  // .x or .y of every increment
+    out[0] = p;
+    for (int i = 0; i < S; ++i) out[i + 1] = p = p + inc[2 * i];
   }
   __syncthreads();
   // (4) records, one step per lane
@@ -420,12 +426,33 @@ __global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const
     }
   }
   __syncthreads();
-  // (6) in-order scan
+  // (6) in-order scan (scan_code, K1c): the first illegal step rejects, else the sum of code / 255.0 in step order.  The
+  // divisions — ~15 dependent instructions each — are formed one step per lane; lane 0 only adds, eight quotients at a time
+  for (int i = tid; i < S; i += blockDim.x) quot[i] = static_cast<double>(code[i]) / 255.0;
+  __syncthreads();
   if (tid == 0) {
     double cm = 0.0;
     int n_ok = 0;
-    for (int i = 0; i < S; ++i)
-      if (!scan_code(static_cast<double>(code[i]), cm, n_ok)) break;
+    bool stopped = false;
+    for (int base = 0; base < S && !stopped; base += 8) {
+      int c[8];
+      double q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        c[j] = code[min(base + j, S - 1)];
+        q[j] = quot[min(base + j, S - 1)];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (!stopped && base + j < S) {
+          if (c[j] >= 254 || c[j] < 0) {
+            stopped = true;
+          } else {
+            cm += q[j];
+            ++n_ok;
+          }
+        }
+    }
     scan_finish(L, t, local, cm, n_ok);
   }
 }
