@@ -348,7 +348,12 @@ __global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const
     double v = tid == 0 ? L.rs.vx : tid == 1 ? L.rs.vy : L.rs.vtheta;
     double th_i = L.rs.theta;
     double *const out = tid == 0 ? vxs : tid == 1 ? vys : th;
+#if defined(SFW_K1S_ABL) && SFW_K1S_ABL == 4
+    for (int i = 0; i < S; ++i) out[i] = tid == 2 ? th_i + 0.01 * i : v;
+    for (int i = 0; i < 0; ++i) {
+#else
     for (int i = 0; i < S; ++i) {
+#endif
       v = new_velocity(target, v, a_max, dt);
       // lanes 0, 1: the new velocity; lane 2: the heading BEFORE this step's update (ref :586-588 integrate with the old theta)
       out[i] = tid == 2 ? th_i : v;
@@ -360,7 +365,11 @@ __global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const
   // (2) sines and position increments, one step per lane
   for (int i = tid; i < S; i += blockDim.x) {
     double s, c, c2 = 0.0, s2 = 0.0;
+#if defined(SFW_K1S_ABL) && SFW_K1S_ABL == 2  // (ablation builds of tools/k1small_ablation.sh: times only, results wrong)
+    s = th[i]; c = 1.0 - th[i];
+#else
     sincos(th[i], &s, &c);
+#endif
     if (vys[i] != 0.0) sincos(M_PI_2 + th[i], &s2, &c2);  // holonomic term, 0 for the grid
     cs[i] = double2{c, s};
     dxy[i] = double2{(vxs[i] * c + vys[i] * c2) * dt, (vxs[i] * s + vys[i] * s2) * dt};  // ref :586-587
@@ -393,7 +402,11 @@ __global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const
     // ref :643-666 without the costmap and social terms (left-to-right sum order kept)
     const double dx = L.ga.wpx - xs[S], dy = L.ga.wpy - ys[S];
     const double d = dx * dx + dy * dy;
+#if defined(SFW_K1S_ABL) && SFW_K1S_ABL == 3
+    double ang = dy - dx - th_end;
+#else
     double ang = atan2(dy, dx) - th_end;
+#endif
     ang = normalize_angle_f(static_cast<float>(ang), static_cast<float>(-M_PI), static_cast<float>(M_PI));
     ang = fabs(ang) / M_PI;
     const double vel = fabs(L.p.max_vel_x - vxs[S - 1]) / L.p.max_vel_x;
@@ -414,7 +427,11 @@ __global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const
     }
   } else {
     const double inv_res = 1.0 / L.resolution;
+#if defined(SFW_K1S_ABL) && SFW_K1S_ABL == 1
+    for (int task = tid; task < 0; task += blockDim.x) {
+#else
     for (int task = tid; task < S * K; task += blockDim.x) {
+#endif
       const int i = task / K, e = task - i * K;
       const double2 a = cs[i];
       int v = footprint_edge(L, xs[i], ys[i], a.x, a.y, e);
