@@ -120,6 +120,7 @@ struct sfw_planner_s {
   const double *d_pin_rest = nullptr;  // see pinned_rest_table: the stage's table on the device, or null
   int obs_tasks_force = -1;            // SFW_OBS_TASKS=0|1 in the environment of sfw_create: the flat form's laser-point pass as
                                        // one lane per agent / as (agent, segment) tasks, whatever sfw_derive prices (tuning aid)
+  bool clock_cleared = false;          // the stage cleared the clock probe in front of the pose rollout it started
   bool pin_rest_on = true;             // SFW_PIN_REST=0 in the environment of sfw_create: no such table (tests: what it changes)
   size_t st_pin_doubles = 0;           // its length (4 + A) when the last stage built one
   std::vector<double> st_pin_pos;      // ... and what it was built from (sfw_set_params between stage and launch rebuilds it)
@@ -755,6 +756,12 @@ int plan_tables(sfw_handle h, bool may_start_poses = false) {
     sfw_launch L;
     fill_launch(h, L, 0, T, T);
     if (!sfw_rollout_is_fused(L)) {  // (the fused small-grid K1 is one launch with the costmap part, and may capture points)
+      h->clock_cleared = false;
+      if (h->timing) {  // the clock probe of a timed launch is cleared here, in front of the rollout (launch_common)
+        SFW_HIP(h, h->clock.reserve(4));
+        SFW_HIP(h, hipMemsetAsync(h->clock.p, 0, 4 * sizeof(unsigned long long), h->stream));
+        h->clock_cleared = true;
+      }
       if (h->timing) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
       h->early_poses_timed = h->timing;
       SFW_HIP(h, sfw_launch_rollout_poses(L, h->stream));
@@ -917,9 +924,12 @@ int launch_common(sfw_handle h) {
   h->early_poses = false;                                 // ... once: a second launch of the same stage rolls out again
   if (timing) {
     SFW_HIP(h, h->clock.reserve(4));
-    SFW_HIP(h, hipMemsetAsync(h->clock.p, 0, 4 * sizeof(unsigned long long), h->stream));
+    // (cleared by the stage already when it started the pose rollout: in front of it, where the GPU waits for the host's
+    // planning anyway, instead of between the rollout and the first K2 dispatch)
+    if (!(poses_done && h->clock_cleared)) SFW_HIP(h, hipMemsetAsync(h->clock.p, 0, 4 * sizeof(unsigned long long), h->stream));
     if (!poses_done) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
   }
+  h->clock_cleared = false;
   const bool single = chunk >= T;
   h->n_chunks = static_cast<int>((T + chunk - 1) / chunk);
   if (!single && timing) {
@@ -963,11 +973,11 @@ int launch_common(sfw_handle h) {
     if (prefix) {
       // K1a -> { K2 prefix phase on the main stream  ||  K1b + K1c on the side stream } -> K2 suffix phase.
       // The prefix phase needs the robot-step table only and under-fills the GPU (one item per class).
+      // The levels are the critical path and are enqueued FIRST; the footprint checks only have to be done when the suffix
+      // launch starts, so their stream gets its work afterwards (enqueued in front of the levels — round 4 — the four
+      // side-stream calls delayed the first level by the host time they take: ~15 us of cfg2's 630 us step).
       if (!poses_done) SFW_HIP(h, sfw_launch_rollout_poses(L, h->stream));
       SFW_HIP(h, hipEventRecord(h->ev_poses, h->stream));
-      SFW_HIP(h, hipStreamWaitEvent(h->side, h->ev_poses, 0));
-      SFW_HIP(h, sfw_launch_rollout_costmap(L, h->side));
-      SFW_HIP(h, hipEventRecord(h->ev_side, h->side));
       if (timing) SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
       const sfw_planner_s::chunk_plan &cp = h->prefix_chunks[static_cast<size_t>(c)];
       const int32_t *tab = h->d_cls.p;
@@ -992,6 +1002,13 @@ int launch_common(sfw_handle h) {
         L.out_state = h->cls_state[l & 1].p;
         L.out_dead = h->cls_dead[l & 1].p;
         SFW_HIP(h, launch_social_of(L, h->stream));
+      }
+      {  // K1b + K1c beside the levels (they wait for the pose rollout, not for the levels)
+        sfw_launch Lc = L;
+        Lc.phase = SFW_PHASE_WHOLE;
+        SFW_HIP(h, hipStreamWaitEvent(h->side, h->ev_poses, 0));
+        SFW_HIP(h, sfw_launch_rollout_costmap(Lc, h->side));
+        SFW_HIP(h, hipEventRecord(h->ev_side, h->side));
       }
       SFW_HIP(h, hipStreamWaitEvent(h->stream, h->ev_side, 0));
       L.phase = SFW_PHASE_SUFFIX;
