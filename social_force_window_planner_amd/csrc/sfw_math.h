@@ -1,7 +1,7 @@
 // sfw_math.h — device math for the social-force pair term, written for the
 // gfx950 vector ALU: no special-case branches, hardware rcp/rsq seeds refined by
-// one Newton step, short Horner polynomials.  Accuracy targets: double ~1e-12
-// relative (the parity tests hold the whole path to 1e-9), float ~1e-7.
+// one Newton step, short Horner polynomials.  Accuracy targets: double ~5e-14
+// relative (asin 7 / exp 9; the parity tests hold the whole path to 1e-9), float ~1e-7.
 // Coefficients: tools/gen_poly.py.
 #ifndef SFW_MATH_H_
 #define SFW_MATH_H_
@@ -12,7 +12,9 @@ namespace sfwm {
 
 // Degrees of the two f64 polynomials of the pair term (tuning knobs, csrc/Makefile EXTRA; tools/gen_poly.py prints the
 // coefficient sets and their errors).  Every VALU instruction of the pair loop costs one 4-cycle issue slot, so a degree
-// is an issue slot per evaluation: asin 7 / exp 8 keep the pair term at ~1e-12 relative — the parity tests hold the whole
+// is an issue slot per evaluation.  asin 7 / exp 9 (round 5) put the pair term at ~5e-14 relative; with exp 8 (rounds 3-4,
+// ~1e-12, 1.6 % less of K2) four random scenes in 6000 — chaotic 0.25 s-Euler crowds — deviated by more than 50 x the oracle's
+// own conditioning, with degree 9 none (profiles/r04_sweep_degrees.txt, r05_parity_sweep.txt).  The parity tests hold the whole
 // rollout to 1e-9, the north star asks for 1e-4.
 #ifndef SFW_ASIN_DEG
 #define SFW_ASIN_DEG 7

@@ -514,8 +514,9 @@ def test_single_sample_and_single_step(oracle_mod, hip_mod):
 ])
 def test_f64_strict_mode(oracle_mod, hip_mod, name, kw):
     """the parity margin round 3 spent on the polynomial degrees is a caller's choice.  The strict mode meets
-    the oracle like the default mode (1e-9 asserted, identical sentinels and selection) and closer (its pair term is at
-    ~1e-14 where the default's is at ~1e-12); both organisations are bit-identical in it too."""
+    the oracle like the default mode (1e-9 asserted, identical sentinels and selection) and a little closer (its pair term is
+    at ~1e-14 where the default's — degree 9 for the exponential since round 5, 7 for the angle — is at ~5e-14; ~1e-12 until
+    round 4); both organisations are bit-identical in it too."""
     from social_force_window_planner_amd._abi import SFW_K2_FLAT, SFW_K2_REGISTER
 
     w = dataclasses.replace(syn.WORKLOADS[name], **kw)
