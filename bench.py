@@ -65,6 +65,7 @@ def parse_args():
     ap.add_argument("--inproc-child", default=None, help=argparse.SUPPRESS)  # workload:devices:exchange:steps:warmup
     ap.add_argument("--inproc-timeout", type=float, default=180.0,
                     help="N > 1: wall-clock limit of each one-process multi-device measurement (run in a child process)")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)  # rank launch only (CPU test)
     ap.add_argument("--grid", default=None, help="override the sample grid, e.g. 512x512 (experiments only)")
     ap.add_argument("--verify", action="store_true", help=argparse.SUPPRESS)  # the default since round 4 (kept for old command lines)
     ap.add_argument("--no-verify", action="store_true",
@@ -78,6 +79,77 @@ def parse_args():
     ap.add_argument("--resident", action="store_true",
                     help="time launch + selection fetch only (no stage, no cost-vector D2H): kernel tuning aid")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def ensure_ranks(args):
+    """`--gpus N` MEANS N ranks, one per GPU (rows are the sharded axis, ref src/sfw_planner.cpp:345).
+    * WORLD_SIZE unset and N > 1: this process becomes the launcher — it re-executes the same command line under
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on a free port of 127.0.0.1 and exits with the
+      launcher's status; rank 0 of the children prints the one JSON line (stdout is inherited).
+    * WORLD_SIZE set (the driver's torchrun form) and != N: exit 2 with a message — never a mislabelled line.
+    * backend nccl with fewer than N visible devices: exit 2 (a `--gpus 8` command must not print `n_gpus: 1`).
+    Returns only in a process that is one of exactly N ranks."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: the launcher's rank count and --gpus "
+                             "disagree; refusing to print a line labelled with either\n")
+            sys.exit(2)
+        return
+    if args.gpus == 1:
+        return
+    if args.backend == "nccl" and not args.launch_check:
+        import torch
+
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} over RCCL needs {args.gpus} visible devices, this node shows "
+                             f"{n_dev}; nothing measured\n")
+            print(json.dumps({"error": f"--gpus {args.gpus} but {n_dev} device(s) visible", "n_gpus_requested": args.gpus,
+                              "visible_devices": n_dev}))
+            sys.exit(2)
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SFW_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write(f"bench.py: --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks: {' '.join(cmd)}\n")
+    sys.stderr.flush()
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def launch_check(args, rank, world, local_rank):
+    """--launch-check: the rank launch alone, no scoring (runs without a GPU; tests/test_bench_launch.py): every rank joins
+    the process group, rank 0 prints what the group is."""
+    info = {"launch_check": True, "n_gpus": world, "gpus_arg": args.gpus,
+            "launched_by": "bench.py (self-launch)" if os.environ.get("SFW_BENCH_SELF_LAUNCHED") else
+                           ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "python")}
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "pid": os.getpid()})
+        info["ranks"] = seen
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        info["ranks"] = [{"rank": 0, "local_rank": 0, "pid": os.getpid()}]
+    if rank == 0:
+        print(json.dumps(info), flush=True)
 
 
 def cpu_baseline(scene, params_kw, budget_s=12.0):
@@ -513,6 +585,18 @@ def executed_share_of(job):
     return (plan["class_steps"] + plan["samples"] * (S - plan["split_step"])) / total
 
 
+def k2_kernel_name(plan, precision, has_points):
+    """The K2 kernel family that dominated the launch, from sfw_grid_plan_info().organisation (SFW_ORG_*: 1 / 2 = register
+    form with one / two slots per lane, 3 = flat form) — the name the rocprofv3 kernel rows of profiles/ start with."""
+    ty = "float" if precision == "f32" else "double"
+    org = plan["organisation"]
+    if org == 3:
+        return f"sfw_social_kernel_flat<{ty}, ..., OBS={'true' if has_points else 'false'}>"
+    if org in (1, 2):
+        return f"sfw_social_kernel<{ty}, NS={org}, ...>" + (" + flat-form side launch" if plan.get("flat_samples") else "")
+    return "sfw_no_social_kernel (robot alone)"
+
+
 def roofline_for(job, k2_ms, precision, brief=False):
     from social_force_window_planner_amd import synthetic as syn
 
@@ -534,7 +618,7 @@ def roofline_for(job, k2_ms, precision, brief=False):
     tr = measured_traffic(job.workload.name) if (precision == "f64" and not GRID_OVERRIDE) else None
     return {
         "bound": "valu",
-        "kernel": "sfw_social_kernel<%s>" % ("float" if precision == "f32" else "double"),
+        "kernel": k2_kernel_name(plan, precision, w.n_obstacles > 0),
         "achieved": ach,
         "peak": peak,
         "unit": "TFLOP/s",
@@ -621,9 +705,13 @@ def main():
             res = {"error": repr(e)}
         print(json.dumps(res), flush=True)
         return
+    ensure_ranks(args)  # --gpus N means N ranks: re-launches itself under torch.distributed.run, or refuses a mismatch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        launch_check(args, rank, world, local_rank)
+        return
     import torch
 
     if not torch.cuda.is_available():
@@ -830,9 +918,45 @@ def main():
     if extra:
         out["extra"] = extra
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(scale_record_first(out, args, ctx)))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def scale_record_first(out, args, ctx):
+    """The line in the order a reader of a SCALE record needs it: metric / value / n_gpus, then `launch` (how many ranks
+    really ran, who launched them, every rank's device) and `cfg5_strong` (BASELINE.json config 5, the configuration the
+    1/2/4/8 curve is quoted on; the full entry stays under extra.cfg5_strong), then everything else."""
+    import torch
+
+    co = out.get("collective")
+    launch = {
+        "world_size": co["world_size"] if co else 1,
+        "gpus_arg": args.gpus,
+        "launched_by": ("bench.py --gpus N (self-launch under torch.distributed.run)" if os.environ.get("SFW_BENCH_SELF_LAUNCHED")
+                        else "torch.distributed.run" if "WORLD_SIZE" in os.environ else "python (single process)"),
+        "backend": co["backend"] if co else None,
+        "visible_devices": torch.cuda.device_count(),
+        "rank_devices": co["rank_devices"] if co else [{"rank": 0, "device": ctx["device"],
+                                                        "name": torch.cuda.get_device_name(ctx["device"]),
+                                                        "hip_visible": os.environ.get("HIP_VISIBLE_DEVICES")}],
+    }
+    c5 = (out.get("extra") or {}).get("cfg5_strong")
+    brief5 = None
+    if c5:
+        brief5 = {"value": c5["value"], "unit": c5["unit"], "n_gpus": c5["n_gpus"], "scaling": "strong",
+                  "ms_per_step": c5["ms_per_step"], "steps": c5["steps"], "samples_per_gpu": c5["samples_per_gpu"],
+                  "social_kernel_ms_per_rank": c5["per_rank"]["social_kernel_ms"],
+                  "workload": c5["workload"], "full_entry": "extra.cfg5_strong"}
+    first = {}
+    for k in ("metric", "value", "unit", "n_gpus"):
+        first[k] = out[k]
+    first["launch"] = launch
+    first["cfg5_strong"] = brief5
+    for k, v in out.items():
+        if k not in first:
+            first[k] = v
+    return first
 
 
 def _scene_with_grid(job):

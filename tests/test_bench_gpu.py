@@ -37,6 +37,8 @@ def test_single_gpu_line():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["launch"]["world_size"] == 1 and d["launch"]["rank_devices"][0]["device"] == 0
+    assert d["roofline"]["kernel"].startswith("sfw_social_kernel_flat<double")  # the kernel that dominated, from the plan
     assert d["dtype"] == "f64" and d["higher_is_better"] is True
     # the default workload is the configuration the metric is quoted on: the north-star target
     assert d["config"]["workload"].startswith("target: 256x256 (v,w) grid, 50 pedestrians")
@@ -79,14 +81,21 @@ def test_single_gpu_line():
 
 
 def test_two_ranks_on_one_gpu_over_gloo():
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+    # the driver's single-process command shape: NO torchrun around it — `--gpus 2` itself launches the two ranks
+    # (bench.ensure_ranks; tests/test_bench_launch.py covers the launch alone on CPU)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--backend", "gloo", "--no-cpu-baseline", "--extras", "inproc_multi,target_strong", "--inproc-workload", "cfg2",
            "--extra-steps", "3"]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d2 = _last_json(r.stdout)
     assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and sum(d2["per_rank"]["rows"]) == 512
+    # what a reader of a SCALE record needs first: the rank count that really ran, who launched it, every rank's device
+    assert list(d2)[:6] == ["metric", "value", "unit", "n_gpus", "launch", "cfg5_strong"]
+    la = d2["launch"]
+    assert la["world_size"] == 2 and la["gpus_arg"] == 2 and la["launched_by"].startswith("bench.py")
+    assert sorted(x["rank"] for x in la["rank_devices"]) == [0, 1]
     assert abs(d2["config"]["samples_per_gpu"] - 65536) < 0.15 * 65536  # blocks of equal planned work, not of equal row counts
     assert len(d2["per_rank"]["social_kernel_ms"]) == 2 and min(d2["per_rank"]["exchange_us"]) > 0
     assert len(d2["per_rank"]["executed_share"]) == 2 and all(0 < v <= 1 for v in d2["per_rank"]["executed_share"])
