@@ -362,6 +362,7 @@ class GridJob:
         self.n_scored = self.n_local - zero  # the (0,0) sample is never scored (ref :349-352)
         self.scorer.stage(self.scene.robot_state, self.lin, self.ang, self.scene.goal_args, self.index_base)
         self.plan = self.scorer.plan_info()
+        self._cost_buf = None
 
     def step(self, resident=False):
         s, sc = self.scorer, self.scene
@@ -370,7 +371,11 @@ class GridJob:
             return s.fetch(want_costs=False)
         s.stage(sc.robot_state, self.lin, self.ang, sc.goal_args, self.index_base)
         s.launch()
-        return s.fetch(want_costs=True)
+        # the caller's cost buffer, the same every cycle (as a C caller's): a fresh 0.5 MB numpy array per step is an mmap and
+        # its page faults inside the blocking call
+        if self._cost_buf is None or self._cost_buf.size != self.n_local:
+            self._cost_buf = np.empty(self.n_local, dtype=np.float64)
+        return s.fetch(want_costs=True, out=self._cost_buf)
 
 
 def run_config(workload_name, precision, steps, warmup, ctx, scaling="weak", resident=False):

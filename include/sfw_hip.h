@@ -290,6 +290,14 @@ int sfw_plan_shared_prefix(const double *linvels, int32_t nv,
                            int32_t n_agents, int32_t *level_ends,
                            int64_t *level_classes, int32_t cap,
                            int32_t *n_levels);
+/* One axis of that plan (host only; diagnostics and tests): the classes of `n` target velocities whose first p clipped
+ * velocities (computeNewVelocity, sfw_planner.hpp:457-463, from the current velocity v0 under a_max, dt) are bit-equal,
+ * for p = 1 .. *n_levels <= max_p (the walk stops once every target is its own class).  counts[p-1] = classes of level
+ * p; classes (nullable) receives [level][n] class ids, numbered in target order.  form 0: the planner's own choice (the
+ * closed form over the two "not yet reached" groups where its premises hold — *closed_form says so —, else the generic
+ * walk of every target's recurrence); form 1: the generic walk.  Both give the same classes. */
+int sfw_plan_axis_classes(const double *targets, int32_t n, double v0, double a_max, double dt, int32_t max_p,
+                          int32_t form, int32_t *counts, int32_t *classes, int32_t *n_levels, int32_t *closed_form);
 /* Contiguous blocks of linvel rows of about equal PLANNED work for R ranks (host only): row0[0..R], rank r takes rows
  * [row0[r], row0[r+1]).  The share of steps the shared-prefix tree saves differs along the row axis (BASELINE cfg5 cut
  * into 8 equal blocks integrates 64..76 % of its steps per block), so equal row counts are unequal work; the cuts follow

@@ -164,6 +164,7 @@ EXPORTED_SYMBOLS = (
     "sfw_grid_plan_info",
     "sfw_plan_shared_prefix",
     "sfw_plan_row_blocks",
+    "sfw_plan_axis_classes",
     "sfw_set_k2_form",
     "sfw_set_timing",
     "sfw_last_launch_ms",

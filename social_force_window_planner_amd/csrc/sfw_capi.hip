@@ -147,6 +147,10 @@ struct sfw_planner_s {
   int skip_zero = 1;
   int64_t index_base = 0;
   bool staged = false, launched = false, launched_timed = false;
+  bool mirrored = false;              // the last launch's selection kernels left costs + record in pin_mirror (sfw_launch_argmin)
+  size_t mirror_max_bytes = size_t(64) << 20;  // SFW_MIRROR_MAX_MB in the environment of sfw_create; 0: always copy
+  long spin_us = 20000;               // SFW_SPIN_US in the environment of sfw_create: how long a fetch polls the stream before
+                                      // it blocks in hipStreamSynchronize (0: block at once)
   bool timing = false;  // sfw_set_timing: record the per-kernel events sfw_last_launch_ms reads
   int k2_form = SFW_K2_AUTO;     // sfw_set_k2_form / SFW_FORCE_FLAT
   // shape of the device the launch heuristics are scaled to: compute units (hipDeviceProp_t.multiProcessorCount: 256 on a
@@ -180,6 +184,10 @@ struct sfw_planner_s {
   int prefix_S = 0;
   int64_t prefix_chunk = 0;
   int64_t prefix_class_steps = 0, prefix_last_classes = 0;
+  std::vector<int32_t> cls_ints;        // the plan's class tables as planned on the host (level_tables offsets index it)
+  int64_t cls_max = 0;                  // largest class count of a level (sizes cls_state / cls_dead)
+  bool cls_two = false;                 // more than one level: both ping-pong buffers
+  const int32_t *d_cls_tab = nullptr;   // ... on the device: inside `world` (staged with the arena) or d_cls (re-planned at launch)
   dev_buf<int32_t> d_cls, cls_dead[2];
   dev_buf<sfw_cls_agent> cls_state[2];  // ping-pong between levels
   std::vector<int> prefix_env;          // SFW_PREFIX: empty automatic, {0} off, else forced split steps
@@ -208,6 +216,7 @@ struct sfw_planner_s {
   uint64_t params_epoch = 1, plan_epoch = 0;
   size_t table_budget_bytes = size_t(8) << 30;  // K1->K2 per-step tables per chunk (of 288 GB): BASELINE cfg4 runs in one chunk
   pinned_buf pin_map, pin_world, pin_out, pin_cls;
+  pinned_buf pin_mirror;  // costs + selection record as the selection kernels of the last launch leave them (device writes)
 };
 
 namespace {
@@ -243,6 +252,25 @@ bool all_finite(const double *v, size_t n) {
   for (size_t i = 0; i < n; ++i)
     if (!std::isfinite(v[i])) return false;
   return true;
+}
+
+// Wait for the handle's stream.  hipStreamSynchronize parks the thread on an interrupt once its short active wait is over,
+// and waking up costs 10-20 us — of a 100 us control cycle or a 600 us grid; the blocking call polls the stream instead
+// (one core busy for the duration of the launch, as a caller asking hipDeviceScheduleSpin would have it) for up to spin_us,
+// then blocks.
+hipError_t wait_stream(sfw_handle h) {
+  if (h->spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(h->stream);
+      if (e != hipErrorNotReady) return e;
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > h->spin_us) break;
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  }
+  return hipStreamSynchronize(h->stream);
 }
 
 // the register-form K2 addresses a sample's record inside a row of the K1->K2 table by a 32-bit byte offset
@@ -335,11 +363,13 @@ double new_velocity_host(double vg, double vi, double a_max, double dt) {
 // Classes of the samples' velocity sequences after 1..max_p steps: cls[p-1][i] is the class of
 // sample value i when the first p velocities are compared, counts[p-1] the number of classes.
 // Stops early once every value is its own class (nothing left to share from there on): cls/counts
-// may hold fewer than max_p levels.  Runs on the control-cycle path, so it avoids a sort per level:
-// new_velocity is monotone in the target (and in the previous velocity), hence so is every v_p, and
-// the samples that share a sequence are CONTIGUOUS when ordered by target — one sort up front, then a
-// run-length pass per level.  (Were they not, the result would only be more classes, never a wrong
-// merge: two samples share a class only if all their compared velocities are bit-equal.)
+// may hold fewer than max_p levels.  new_velocity is monotone in the target (and in the previous
+// velocity), hence so is every v_p, and the samples that share a sequence are CONTIGUOUS when ordered
+// by target — one sort up front, then a run-length pass per level.  (Were they not, the result would
+// only be more classes, never a wrong merge: two samples share a class only if all their compared
+// velocities are bit-equal.)  This is the GENERIC form — every sample walks the recurrence —, the
+// definition the closed form below (axis_classes::build_fast) is tested against
+// (tests/test_prefix_plan.py) and the fallback for the inputs that form does not take.
 void velocity_classes(const std::vector<double> &targets, double v0, double a_max, double dt, int max_p,
                       std::vector<std::vector<int32_t>> &cls, std::vector<int32_t> &counts) {
   const size_t n = targets.size();
@@ -385,9 +415,22 @@ double step_cost(double items, double items_per_wave, int cus) {
 }
 
 // Classes of ONE axis of the grid (velocity_classes of the linear or of the angular targets).
+//
+// The planning sits on the blocking call's critical path (the GPU has nothing but the pose rollout to do until the class
+// tables arrive: profiles/r05_step_timeline_cfg2.txt), and the generic form above walks n x max_p recurrence steps and
+// allocates a class vector per step count — 26 us for cfg2's 128 + 128 targets, 52 us for the target configuration's.
+// Closed form (build_fast): with s = a_max dt > 0 every sample that has not reached its target yet carries the SAME
+// velocity — u_p = fl(u_{p-1} + s) above the start velocity, d_p = fl(d_{p-1} - s) below it — and a sample that has
+// reached its target keeps it:  v_p(t) = t - v0 >= 0 ? fmin(t, u_p) : fmax(t, d_p)  (induction over new_velocity_host's
+// two branches; the reached sample takes the first branch with vg - vi == 0 and fmin(t, fl(t + s)) = t).  In target
+// order the classes of level p are therefore
+//     [0, lo_p) all t <= d_p : ONE class | [lo_p, hi_p) reached: one class per distinct target | [hi_p, n) all t >= u_p : ONE class
+// with lo_p falling and hi_p rising in p: two pointers, O(n + max_p) for all the class COUNTS (what the level choice needs),
+// and the class array of a level is written only when a chosen level asks for it (level()).  Taken only when the model's
+// premises hold — s > 0, u and d really move at every step (no stall at an ulp), no -0.0 among the targets (the generic form
+// compares bits) —, otherwise the generic form runs.  Same classes, same numbering (in target order) as the generic form.
 struct axis_classes {
-  std::vector<std::vector<int32_t>> c;  // per number of compared steps: class of every value
-  std::vector<int32_t> n;               // class counts
+  std::vector<int32_t> n;               // class counts per number of compared steps (index p - 1)
   // what they were derived from (a shared copy is only reused for exactly these inputs)
   std::vector<double> targets;
   double v0 = 0, a_max = 0, dt = 0;
@@ -395,15 +438,126 @@ struct axis_classes {
   bool made_for(const std::vector<double> &t, double v0_, double a_, double dt_, int mp) const {
     return v0 == v0_ && a_max == a_ && dt == dt_ && max_p == mp && targets == t;
   }
+  // class of every value when the first p velocities are compared (p >= 1; past the last computed level: that level, where
+  // every value is its own class)
+  const std::vector<int32_t> &level(int p) const {
+    const size_t l = std::min<size_t>(static_cast<size_t>(p), n.size()) - 1;
+    if (!fast) return c[l];
+    if (c[l].empty()) write_level(l);
+    return c[l];
+  }
+  // (a copy lent to several threads — sfw_multi_score_grid's column axis — is completed first: level() then only reads)
+  void complete() const {
+    if (fast)
+      for (size_t l = 0; l < n.size(); ++l)
+        if (c[l].empty()) write_level(l);
+  }
+  bool fast = false;
+
+  void build(bool allow_fast) {
+    fast = allow_fast && build_fast();
+    if (!fast) {
+      c.clear();
+      velocity_classes(targets, v0, a_max, dt, max_p, c, n);
+    }
+  }
+
+ private:
+  mutable std::vector<std::vector<int32_t>> c;  // generic: every level; fast: the levels asked for so far
+  std::vector<int32_t> order;                   // fast: target order -> value index
+  std::vector<int32_t> run;                     // fast: run (distinct bit pattern) of every position in target order, from 0
+  std::vector<int32_t> lo, hi;                  // fast: per level
+  static uint64_t bits_of(double x) {
+    uint64_t b;
+    std::memcpy(&b, &x, sizeof(b));
+    return b;
+  }
+  bool build_fast() {
+    const size_t cnt = targets.size();
+    n.clear();
+    c.clear();
+    lo.clear();
+    hi.clear();
+    if (cnt == 0 || max_p < 1) return false;
+    const double s = a_max * dt;
+    if (!(s > 0.0) || !std::isfinite(s) || !std::isfinite(v0)) return false;
+    for (double t : targets)
+      if (!std::isfinite(t) || bits_of(t) == (uint64_t(1) << 63)) return false;
+    order.resize(cnt);
+    bool sorted = true;
+    for (size_t i = 0; i < cnt; ++i) {
+      order[i] = static_cast<int32_t>(i);
+      if (i && targets[i] < targets[i - 1]) sorted = false;
+    }
+    if (!sorted)
+      std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return targets[static_cast<size_t>(a)] != targets[static_cast<size_t>(b)] ? targets[static_cast<size_t>(a)] < targets[static_cast<size_t>(b)]
+                                                                                    : a < b;
+      });
+    auto t_at = [&](size_t k) { return targets[static_cast<size_t>(order[k])]; };
+    run.resize(cnt);
+    int32_t r = 0;
+    for (size_t k = 0; k < cnt; ++k) {
+      if (k && bits_of(t_at(k)) != bits_of(t_at(k - 1))) ++r;
+      run[k] = r;
+    }
+    size_t m = 0;  // first position of the side that accelerates (vg - vi >= 0 at the start velocity)
+    while (m < cnt && !((t_at(m) - v0) >= 0)) ++m;
+    double u = v0, d = v0;
+    size_t l = m, h = m;  // lo_p / hi_p: the reached zone [l, h) grows from the start velocity outwards
+    for (int p = 0; p < max_p; ++p) {
+      // the recurrence's own expressions (new_velocity_host): vi + a_max * dt, vi - a_max * dt
+      const double un = u + a_max * dt, dn = d - a_max * dt;
+      if (!(un > u) || !(dn < d) || !std::isfinite(un) || !std::isfinite(dn)) return false;  // stalled at an ulp: generic form
+      u = un;
+      d = dn;
+      while (h < cnt && t_at(h) < u) ++h;       // t < u_p: reached (fmin(t, u_p) = t); t >= u_p: carries u_p
+      while (l > 0 && t_at(l - 1) > d) --l;     // t > d_p: reached; t <= d_p: carries d_p
+      lo.push_back(static_cast<int32_t>(l));
+      hi.push_back(static_cast<int32_t>(h));
+      // classes: the group below (if any) + the distinct targets in [l, h) + the group above (if any).  A target equal to
+      // u_p (d_p) carries the group's value: it sits in the group (h stops in front of it)
+      int32_t classes = (l > 0 ? 1 : 0) + (h < cnt ? 1 : 0);
+      if (h > l) classes += run[h - 1] - run[l] + 1;
+      n.push_back(classes);
+      if (static_cast<size_t>(classes) == cnt) break;
+    }
+    c.assign(n.size(), std::vector<int32_t>());
+    return true;
+  }
+  void write_level(size_t lv) const {
+    const size_t cnt = targets.size();
+    const size_t l = static_cast<size_t>(lo[lv]), h = static_cast<size_t>(hi[lv]);
+    std::vector<int32_t> &out = c[lv];
+    out.resize(cnt);
+    const int32_t below = l > 0 ? 1 : 0;
+    const int32_t mid = h > l ? run[h - 1] - run[l] + 1 : 0;
+    for (size_t k = 0; k < cnt; ++k) {
+      int32_t id;
+      if (k < l) id = 0;
+      else if (k < h) id = below + (run[k] - run[l]);
+      else id = below + mid;
+      out[static_cast<size_t>(order[k])] = id;
+    }
+  }
 };
-axis_classes classes_of_axis(const std::vector<double> &targets, double v0, double a_max, double dt, int max_p) {
+// SFW_PLAN_GENERIC=1 in the environment: always the generic form (A/B and tests)
+bool plan_fast_allowed() {
+  static const bool on = [] {
+    const char *e = std::getenv("SFW_PLAN_GENERIC");
+    return !(e && e[0] == '1');
+  }();
+  return on;
+}
+axis_classes classes_of_axis(const std::vector<double> &targets, double v0, double a_max, double dt, int max_p,
+                             bool allow_fast = plan_fast_allowed()) {
   axis_classes a;
   a.targets = targets;
   a.v0 = v0;
   a.a_max = a_max;
   a.dt = dt;
   a.max_p = max_p;
-  velocity_classes(targets, v0, a_max, dt, max_p, a.c, a.n);
+  a.build(allow_fast);
   return a;
 }
 int prefix_max_p(int S) { return std::min(S - 1, 48); }
@@ -414,8 +568,6 @@ struct prefix_classes {
   axis_classes rows, own_cols;
   const axis_classes *cols = nullptr;
   int max_p = 0;
-  const std::vector<std::vector<int32_t>> &rc() const { return rows.c; }
-  const std::vector<std::vector<int32_t>> &cc() const { return cols->c; }
   // a level past the last computed one has every value in its own class
   int32_t n_rows_at(int p) const { return rows.n[std::min<size_t>(static_cast<size_t>(p), rows.n.size()) - 1]; }
   int32_t n_cols_at(int p) const { return cols->n[std::min<size_t>(static_cast<size_t>(p), cols->n.size()) - 1]; }
@@ -485,7 +637,7 @@ void plan_row_blocks(const std::vector<double> &lin, const std::vector<double> &
   std::vector<double> w(static_cast<size_t>(nv), static_cast<double>(nw) * (S - steps.back()));
   int prev = 0;
   for (int p : steps) {
-    const std::vector<int32_t> &rc = pc.rows.c[std::min<size_t>(static_cast<size_t>(p), pc.rows.c.size()) - 1];
+    const std::vector<int32_t> &rc = pc.rows.level(p);
     const double per_class = static_cast<double>(pc.n_cols_at(p)) * (p - prev);
     for (int64_t i = 0; i < nv; ++i)
       if (i == 0 || rc[static_cast<size_t>(i)] != rc[static_cast<size_t>(i - 1)]) w[static_cast<size_t>(i)] += per_class;
@@ -507,6 +659,8 @@ void plan_row_blocks(const std::vector<double> &lin, const std::vector<double> &
 int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   h->prefix_steps.clear();
   h->prefix_chunks.clear();
+  h->cls_ints.clear();
+  h->cls_max = 0;
   h->prefix_class_steps = h->prefix_last_classes = 0;
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
   const bool forced = !h->prefix_env.empty();
@@ -517,11 +671,9 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   prefix_classes pc;
   classes_of_grid(pc, h->h_lin, h->h_ang, h->rs.vx, h->rs.vtheta, h->ga.acc_x, h->ga.acc_theta, h->params.sim_time / S, S,
                   static_cast<const axis_classes *>(h->shared_cols));
-  const std::vector<std::vector<int32_t>> &rc = pc.rc(), &cc = pc.cc();
+  const axis_classes &rc = pc.rows, &cc = *pc.cols;
   const std::vector<int32_t> &nr = pc.rows.n, &nc = pc.cols->n;
-  auto level = [](const std::vector<std::vector<int32_t>> &c, int p) -> const std::vector<int32_t> & {
-    return c[std::min<size_t>(static_cast<size_t>(p), c.size()) - 1];
-  };
+  auto level = [](const axis_classes &c, int p) -> const std::vector<int32_t> & { return c.level(p); };
   auto count_at = [](const std::vector<int32_t> &n, int p) { return n[std::min<size_t>(static_cast<size_t>(p), n.size()) - 1]; };
   std::vector<int> steps;
   if (forced) {
@@ -559,7 +711,7 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
   };
   struct axis_level { std::vector<int32_t> local, rep, src; };
   // levels of one axis over [i0, i1): local classes, representatives, parent classes
-  auto axis_levels = [&](const std::vector<std::vector<int32_t>> &cls, int64_t i0, int64_t i1) {
+  auto axis_levels = [&](const axis_classes &cls, int64_t i0, int64_t i1) {
     std::vector<axis_level> out(n_lv);
     for (size_t l = 0; l < n_lv; ++l) {
       relabel(level(cls, steps[l]), i0, i1, out[l].local, out[l].rep);
@@ -597,15 +749,11 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
     cp.o_row_cls = append(rows[n_lv - 1].local);
     h->prefix_chunks.push_back(cp);
   }
-  SFW_HIP(h, h->d_cls.reserve(ints.size()));
-  SFW_HIP(h, h->pin_cls.reserve(sizeof(int32_t) * ints.size()));
-  std::memcpy(h->pin_cls.p, ints.data(), sizeof(int32_t) * ints.size());
-  SFW_HIP(h, hipMemcpyAsync(h->d_cls.p, h->pin_cls.p, sizeof(int32_t) * ints.size(), hipMemcpyHostToDevice, h->stream));
-  SFW_HIP(h, h->pin_cls.mark(h->stream));
-  for (size_t b = 0; b < (n_lv > 1 ? 2u : 1u); ++b) {
-    SFW_HIP(h, h->cls_dead[b].reserve(static_cast<size_t>(max_cls)));
-    SFW_HIP(h, h->cls_state[b].reserve(static_cast<size_t>(max_cls) * h->st_A));
-  }
+  // (host only: the tables reach the device with the stage's one arena copy — stage_common — or, when a launch re-plans
+  // after sfw_set_params, by a copy of their own: upload_class_tables)
+  h->cls_ints.swap(ints);
+  h->cls_max = max_cls;
+  h->cls_two = n_lv > 1;
   if (std::getenv("SFW_DEBUG_PLAN")) {
     std::fprintf(stderr, "[sfw] shared prefix, %d x %d samples, S=%d, %zu chunk(s):", h->nv, h->nw, S, h->prefix_chunks.size());
     for (size_t l = 0; l < n_lv; ++l)
@@ -736,10 +884,8 @@ bool pinned_rest_table(const sfw_params &p, const sfw_robot_state &rs, const dou
 
 // Everything of a stage that depends on sfw_params: the K1->K2 tables ([S][chunk] records, chunk bounded
 // by the table budget) and the shared-prefix plan (classes of the velocity sequences under dt = sim_time/S).
-// Run by every stage, and again by a launch when sfw_set_params came in between (the reference re-reads
-// its parameters every cycle, :125): a plan made for another dt would merge samples whose robot
-// trajectories now differ.
-int plan_tables(sfw_handle h, bool may_start_poses = false) {
+// Host half: chunk size under the table budget and the shared-prefix plan (class tables in h->cls_ints).  No device call.
+int64_t plan_tables_host(sfw_handle h, int *err) {
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
   const int S = num_steps_of(h->params);
   h->early_poses = false;
@@ -748,11 +894,24 @@ int plan_tables(sfw_handle h, bool may_start_poses = false) {
   if (chunk < 1024) chunk = 1024;
   if (chunk > kRowLimit) chunk = kRowLimit;
   if (chunk > T) chunk = T;
+  *err = plan_prefix(h, chunk, S);
+  h->plan_epoch = h->params_epoch;
+  return chunk;
+}
+// Device half: the K1->K2 tables and the class-record buffers; with may_start_poses the pose rollout of a single-chunk grid
+// is enqueued here, by the STAGE (the robot's poses depend on the sample vectors alone).
+int plan_tables_device(sfw_handle h, int64_t chunk, bool may_start_poses) {
+  const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
+  const int S = num_steps_of(h->params);
   SFW_HIP(h, h->rstep.reserve(static_cast<size_t>(chunk) * S));
   SFW_HIP(h, h->frame.reserve(static_cast<size_t>(chunk) * S));
   SFW_HIP(h, h->fcode.reserve(static_cast<size_t>(chunk) * S));
+  if (!h->prefix_steps.empty())
+    for (size_t b = 0; b < (h->cls_two ? 2u : 1u); ++b) {
+      SFW_HIP(h, h->cls_dead[b].reserve(static_cast<size_t>(h->cls_max)));
+      SFW_HIP(h, h->cls_state[b].reserve(static_cast<size_t>(h->cls_max) * h->st_A));
+    }
   if (may_start_poses && chunk >= T) {
-    // the robot's poses depend on the sample vectors alone: the GPU rolls them out while the host plans the prefix tree
     sfw_launch L;
     fill_launch(h, L, 0, T, T);
     if (!sfw_rollout_is_fused(L)) {  // (the fused small-grid K1 is one launch with the costmap part, and may capture points)
@@ -768,9 +927,29 @@ int plan_tables(sfw_handle h, bool may_start_poses = false) {
       h->early_poses = true;
     }
   }
-  if (int e = plan_prefix(h, chunk, S)) return e;
-  h->plan_epoch = h->params_epoch;
   return SFW_OK;
+}
+// The class tables by a copy of their own (a launch that re-plans after sfw_set_params: the stage's arena is on the device already)
+int upload_class_tables(sfw_handle h) {
+  h->d_cls_tab = nullptr;
+  if (h->cls_ints.empty()) return SFW_OK;
+  const size_t bytes = sizeof(int32_t) * h->cls_ints.size();
+  SFW_HIP(h, h->d_cls.reserve(h->cls_ints.size()));
+  SFW_HIP(h, h->pin_cls.reserve(bytes));
+  std::memcpy(h->pin_cls.p, h->cls_ints.data(), bytes);
+  SFW_HIP(h, hipMemcpyAsync(h->d_cls.p, h->pin_cls.p, bytes, hipMemcpyHostToDevice, h->stream));
+  SFW_HIP(h, h->pin_cls.mark(h->stream));
+  h->d_cls_tab = h->d_cls.p;
+  return SFW_OK;
+}
+// Everything of a stage that depends on sfw_params, redone by a launch when sfw_set_params came in between (the reference
+// re-reads its parameters every cycle, :125): a plan made for another dt would merge samples whose robot trajectories now differ.
+int replan_at_launch(sfw_handle h) {
+  int err = SFW_OK;
+  const int64_t chunk = plan_tables_host(h, &err);
+  if (err) return err;
+  if (int e = plan_tables_device(h, chunk, false)) return e;
+  return upload_class_tables(h);
 }
 
 // The agent / laser-point set must fit one wave's LDS allocation (160 KiB per CU).
@@ -797,7 +976,25 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   SFW_HIP(h, hipSetDevice(h->device));
   h->h_lin.assign(lin, lin + nv);
   h->h_ang.assign(ang, ang + nw);
-  {  // one arena, one copy: footprint | agents blob | linvels | angvels
+  h->st_K = h->K;
+  h->st_A = h->A;
+  h->st_O = h->O;
+  h->st_NG = h->NG;
+  h->st_n_grp_mem = h->n_grp_mem;
+  h->nv = nv;
+  h->nw = nw;
+  h->rs = *rs;
+  h->ga = *args;
+  h->vy_samp = vy_samp;
+  h->skip_zero = skip_zero;
+  h->index_base = index_base;
+  // The shared-prefix plan FIRST, on the host (a few microseconds since round 6: axis_classes): its class tables ride in the
+  // stage's one arena copy and the levels can be enqueued right behind the pose rollout.  (Rounds 1-5 planned behind the
+  // arena copy and the pose rollout, 25-50 us, and sent the tables in a second copy the first level then waited for.)
+  int plan_err = SFW_OK;
+  const int64_t chunk = plan_tables_host(h, &plan_err);
+  if (plan_err) return plan_err;
+  {  // one arena, one copy: footprint | agents blob | linvels | angvels | relative-rest terms | pinned-rest table | class tables
     auto up16 = [](size_t b) { return (b + 15) & ~size_t(15); };
     const bool rest = !h->rest_pairs.empty();
     const size_t o_fp = 0, o_ag = o_fp + up16(sizeof(double) * (h->h_footprint.empty() ? 2 : h->h_footprint.size())),
@@ -807,7 +1004,8 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
                  pin_doubles = 4 + static_cast<size_t>(h->A > 0 ? h->A : 0),
                  // (room for the pinned-rest table whenever the robot stands still at hand-over: whether one is needed is known
                  // once the agents' constants have been looked at, below)
-                 total = o_pin + ((h->pin_rest_on && rs->vx == 0.0 && rs->vy == 0.0 && h->A > 1) ? up16(sizeof(double) * pin_doubles) : 0);
+                 o_cls = o_pin + ((h->pin_rest_on && rs->vx == 0.0 && rs->vy == 0.0 && h->A > 1) ? up16(sizeof(double) * pin_doubles) : 0),
+                 total = o_cls + up16(sizeof(int32_t) * h->cls_ints.size());
     SFW_HIP(h, h->pin_world.reserve(total));
     SFW_HIP(h, h->world.reserve(total));
     char *pb = h->pin_world.p;
@@ -815,6 +1013,7 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     if (!h->h_agents.empty()) std::memcpy(pb + o_ag, h->h_agents.data(), h->h_agents.size());
     std::memcpy(pb + o_lin, lin, sizeof(double) * nv);
     std::memcpy(pb + o_ang, ang, sizeof(double) * nw);
+    if (!h->cls_ints.empty()) std::memcpy(pb + o_cls, h->cls_ints.data(), sizeof(int32_t) * h->cls_ints.size());
     h->st_rest_pairs.clear();
     if (rest) {
       const double *pos = reinterpret_cast<const double *>(h->h_agents.data());
@@ -825,13 +1024,14 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
       rest_forces(h->params, h->rest_pairs, pos, vel, h->A, reinterpret_cast<double *>(pb + o_rest));
     }
     bool pinned = false;
-    if (total > o_pin)
+    if (o_cls > o_pin)
       pinned = pinned_rest_table(h->params, *rs, reinterpret_cast<const double *>(h->h_agents.data()),
                                  reinterpret_cast<const sfw_agent_const *>(h->h_agents.data() + h->ao_cst), h->A,
                                  reinterpret_cast<double *>(pb + o_pin));
     SFW_HIP(h, hipMemcpyAsync(h->world.p, pb, total, hipMemcpyHostToDevice, h->stream));
     SFW_HIP(h, h->pin_world.mark(h->stream));
     const char *db = h->world.p;
+    h->d_cls_tab = h->cls_ints.empty() ? nullptr : reinterpret_cast<const int32_t *>(db + o_cls);
     h->d_pin_rest = pinned ? reinterpret_cast<const double *>(db + o_pin) : nullptr;
     h->st_pin_doubles = pinned ? pin_doubles : 0;
     if (pinned) {
@@ -852,23 +1052,11 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     h->d_angvels = reinterpret_cast<const double *>(db + o_ang);
     h->d_agent_rest = rest ? reinterpret_cast<const double *>(db + o_rest) : nullptr;
   }
-  h->st_K = h->K;
-  h->st_A = h->A;
-  h->st_O = h->O;
-  h->st_NG = h->NG;
-  h->st_n_grp_mem = h->n_grp_mem;
   if (h->pair_tab_A != h->A) {
     SFW_HIP(h, h->pair_tab.reserve(static_cast<size_t>(sfw_pair_table_entries(h->A))));
     SFW_HIP(h, sfw_launch_pair_table(h->pair_tab.p, h->A, h->stream));
     h->pair_tab_A = h->A;
   }
-  h->nv = nv;
-  h->nw = nw;
-  h->rs = *rs;
-  h->ga = *args;
-  h->vy_samp = vy_samp;
-  h->skip_zero = skip_zero;
-  h->index_base = index_base;
   const int64_t T = static_cast<int64_t>(nv) * nw;
   SFW_HIP(h, h->status.reserve(T));
   SFW_HIP(h, h->coll_step.reserve(T));
@@ -876,7 +1064,7 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   SFW_HIP(h, h->costs.reserve(T + (sizeof(sfw_sel) + sizeof(double) - 1) / sizeof(double)));
   h->d_sel = reinterpret_cast<sfw_sel *>(h->costs.p + T);
   SFW_HIP(h, h->partials.reserve(sfw_argmin_partials(T)));
-  if (int e = plan_tables(h, grid)) return e;
+  if (int e = plan_tables_device(h, chunk, grid)) return e;
   h->staged = true;
   h->launched = false;
   return SFW_OK;
@@ -889,7 +1077,7 @@ int launch_common(sfw_handle h) {
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
   // sfw_set_params since the stage: tables and shared-prefix plan are redone for the live parameters
   if (h->plan_epoch != h->params_epoch) {
-    if (int e = plan_tables(h)) return e;  // (also drops the poses the stage started: they were rolled out under the old parameters)
+    if (int e = replan_at_launch(h)) return e;  // (also drops the poses the stage started: they were rolled out under the old parameters)
     if (h->d_agent_rest && !h->st_rest_pairs.empty()) {  // the relative-rest terms depend on the sfm parameters too
       const size_t bytes = sizeof(double) * 2 * static_cast<size_t>(h->st_A);
       SFW_HIP(h, h->pin_cls.wait());
@@ -980,7 +1168,7 @@ int launch_common(sfw_handle h) {
       SFW_HIP(h, hipEventRecord(h->ev_poses, h->stream));
       if (timing) SFW_HIP(h, hipEventRecord(single ? h->ev[1] : h->chunk_ev[3 * c + 1], h->stream));
       const sfw_planner_s::chunk_plan &cp = h->prefix_chunks[static_cast<size_t>(c)];
-      const int32_t *tab = h->d_cls.p;
+      const int32_t *tab = h->d_cls_tab;
       const size_t n_lv = h->prefix_steps.size();
       for (size_t l = 0; l < n_lv; ++l) {  // the tree of shared steps, coarsest classes first
         const sfw_planner_s::level_tables &t = cp.lv[l];
@@ -1030,8 +1218,22 @@ int launch_common(sfw_handle h) {
     if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c + 2], h->stream));
   }
   if (timing) SFW_HIP(h, hipEventRecord(h->ev[2], h->stream));
+  // the cost vector and the selection record reach the host through the selection kernels themselves (pinned mirror): the
+  // fetch then only waits for the stream.  Grids whose vector is larger than SFW_MIRROR_MAX_MB (default 64) keep the copy.
+  h->mirrored = false;
+  double *costs_host = nullptr;
+  sfw_sel *sel_host = nullptr;
+  if (h->mirror_max_bytes > 0 && sizeof(double) * static_cast<size_t>(T) <= h->mirror_max_bytes) {
+    const size_t cost_bytes = sizeof(double) * static_cast<size_t>(T);
+    // (growing it frees the old area: no launch still in the stream may be writing there)
+    if (cost_bytes + sizeof(sfw_sel) > h->pin_mirror.cap) SFW_HIP(h, hipStreamSynchronize(h->stream));
+    SFW_HIP(h, h->pin_mirror.reserve(cost_bytes + sizeof(sfw_sel)));
+    costs_host = reinterpret_cast<double *>(h->pin_mirror.p);
+    sel_host = reinterpret_cast<sfw_sel *>(h->pin_mirror.p + cost_bytes);
+    h->mirrored = true;
+  }
   SFW_HIP(h, sfw_launch_argmin(h->costs.p, h->d_linvels, h->d_angvels, h->nw, T, h->index_base,
-                               h->partials.p, h->d_sel, h->stream));
+                               h->partials.p, h->d_sel, h->stream, costs_host, sel_host));
   if (timing) SFW_HIP(h, hipEventRecord(h->ev[3], h->stream));
   h->launched = true;
   h->launched_timed = timing;
@@ -1123,6 +1325,8 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
   }
   if (const char *b = std::getenv("SFW_FORCE_FLAT")) h->k2_form = std::atoi(b) == 1 ? SFW_K2_FLAT : std::atoi(b) == 0 ? SFW_K2_REGISTER : SFW_K2_AUTO;
   if (const char *b = std::getenv("SFW_PIN_REST")) h->pin_rest_on = std::atoi(b) != 0;
+  if (const char *b = std::getenv("SFW_SPIN_US")) h->spin_us = std::max(0L, std::atol(b));
+  if (const char *b = std::getenv("SFW_MIRROR_MAX_MB")) h->mirror_max_bytes = static_cast<size_t>(std::max(0L, std::atol(b))) << 20;
   if (const char *b = std::getenv("SFW_OBS_TASKS")) h->obs_tasks_force = std::atoi(b) != 0 ? 1 : 0;
   if (const char *b = std::getenv("SFW_TABLE_BUDGET_MB")) {
     long mb = std::atol(b);
@@ -1196,6 +1400,7 @@ int sfw_destroy(sfw_handle h) {
   h->pin_map.release();
   h->pin_world.release();
   h->pin_out.release();
+  h->pin_mirror.release();
   h->pin_cls.release();
   h->d_cls.release();
   for (auto &b : h->cls_dead) b.release();
@@ -1371,14 +1576,21 @@ int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out, sfw_best
   SFW_HIP(h, hipSetDevice(h->device));
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
   // costs and the selection record are contiguous on the device: one copy fetches both
-  const size_t cost_bytes = costs_out ? sizeof(double) * static_cast<size_t>(T) : 0;
-  SFW_HIP(h, h->pin_out.reserve(cost_bytes + sizeof(sfw_sel)));
-  const char *src = reinterpret_cast<const char *>(h->d_sel) - cost_bytes;
-  SFW_HIP(h, hipMemcpyAsync(h->pin_out.p, src, cost_bytes + sizeof(sfw_sel), hipMemcpyDeviceToHost, h->stream));
-  SFW_HIP(h, hipStreamSynchronize(h->stream));
-  if (costs_out) std::memcpy(costs_out, h->pin_out.p, cost_bytes);
   sfw_sel s;
-  std::memcpy(&s, h->pin_out.p + cost_bytes, sizeof(s));
+  if (h->mirrored) {  // the launch's selection kernels wrote both to pin_mirror: nothing to copy, only to wait for
+    const size_t all_bytes = sizeof(double) * static_cast<size_t>(T);
+    SFW_HIP(h, wait_stream(h));
+    if (costs_out) std::memcpy(costs_out, h->pin_mirror.p, all_bytes);
+    std::memcpy(&s, h->pin_mirror.p + all_bytes, sizeof(s));
+  } else {
+    const size_t cost_bytes = costs_out ? sizeof(double) * static_cast<size_t>(T) : 0;
+    SFW_HIP(h, h->pin_out.reserve(cost_bytes + sizeof(sfw_sel)));
+    const char *src = reinterpret_cast<const char *>(h->d_sel) - cost_bytes;
+    SFW_HIP(h, hipMemcpyAsync(h->pin_out.p, src, cost_bytes + sizeof(sfw_sel), hipMemcpyDeviceToHost, h->stream));
+    SFW_HIP(h, wait_stream(h));
+    if (costs_out) std::memcpy(costs_out, h->pin_out.p, cost_bytes);
+    std::memcpy(&s, h->pin_out.p + cost_bytes, sizeof(s));
+  }
   sel_to_best(h, s, best_out, key_out);
   return SFW_OK;
 }
@@ -1452,6 +1664,21 @@ int sfw_plan_shared_prefix(const double *linvels, int32_t nv, const double *angv
   for (size_t l = 0; l < steps.size() && l < static_cast<size_t>(cap); ++l) {
     level_ends[l] = steps[l];
     level_classes[l] = static_cast<int64_t>(pc.n_rows_at(steps[l])) * pc.n_cols_at(steps[l]);
+  }
+  return SFW_OK;
+}
+
+int sfw_plan_axis_classes(const double *targets, int32_t n, double v0, double a_max, double dt, int32_t max_p, int32_t form,
+                          int32_t *counts, int32_t *classes, int32_t *n_levels, int32_t *closed_form) {
+  if (!targets || n <= 0 || max_p < 1 || !counts || !n_levels || (form != 0 && form != 1)) return SFW_ERR_INVALID_ARG;
+  if (!all_finite(targets, static_cast<size_t>(n)) || !std::isfinite(v0) || !std::isfinite(a_max) || !std::isfinite(dt))
+    return SFW_ERR_INVALID_ARG;
+  const axis_classes a = classes_of_axis(std::vector<double>(targets, targets + n), v0, a_max, dt, max_p, form == 0);
+  *n_levels = static_cast<int32_t>(a.n.size());
+  if (closed_form) *closed_form = a.fast ? 1 : 0;
+  for (size_t l = 0; l < a.n.size(); ++l) {
+    counts[l] = a.n[l];
+    if (classes) std::memcpy(classes + l * static_cast<size_t>(n), a.level(static_cast<int>(l) + 1).data(), sizeof(int32_t) * static_cast<size_t>(n));
   }
   return SFW_OK;
 }
@@ -1999,6 +2226,7 @@ int sfw_multi_score_grid(sfw_multi_handle m, const sfw_robot_state *rs, const do
     const int64_t rows_max = (nv + R - 1) / R;
     if (R > 1 && h0->A >= 2 && S >= 2 && rows_max * nw >= 4096 && (h0->prefix_env.empty() || h0->prefix_env[0] != 0)) {
       cols = classes_of_axis(m->ang, rs->vtheta, args->acc_theta, h0->params.sim_time / S, prefix_max_p(S));
+      cols.complete();  // (read by every rank's thread: no level is written lazily from there)
       shared = &cols;
     }
   }

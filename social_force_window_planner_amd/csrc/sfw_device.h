@@ -203,9 +203,11 @@ bool sfw_rollout_is_fused(const sfw_launch &L);
 // Reduces costs[0..T) to one sfw_sel at *out (device memory).  partials must
 // hold >= sfw_argmin_partials(T) records.
 int64_t sfw_argmin_partials(int64_t T);
+// costs_host / sel_host (nullable): host-visible pinned memory that receives a copy of the cost vector and of the record
 hipError_t sfw_launch_argmin(const double *costs, const double *linvels, const double *angvels,
                              int32_t nw, int64_t T, int64_t index_base, sfw_sel *partials,
-                             sfw_sel *out, hipStream_t stream);
+                             sfw_sel *out, hipStream_t stream, double *costs_host = nullptr,
+                             sfw_sel *sel_host = nullptr);
 // Row r of the [R,5] multi-device exchange table from a selection record (+inf in every other row).
 hipError_t sfw_launch_key_table(const sfw_sel *sel, double *table, int r, int R, hipStream_t stream);
 // Pair table of the flat social kernel for A agents: sfw_pair_table_entries(A) uint16 entries.

@@ -250,6 +250,112 @@ __global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
   });
 }
 
+// K1a again, for GPU-filling grids: TEAMS of eight lanes per sample, eight samples per wave.  One thread per sample leaves a
+// lone wave per SIMD (cfg2: 256 waves on 1024 SIMDs) walking S serial steps, each with a library sincos — 19 us at the head
+// of cfg2's blocking call, 31 us at the target configuration's (profiles/r05_step_timeline_cfg2.txt).  As in the small-grid
+// kernel below only the true recurrences stay serial; the steps are taken in rounds of eight, one step per lane of the team:
+//   (1) lanes 0, 1, 2 of a team: the round's eight steps of the three velocity recurrences (computeNewVelocity, ref :581-583),
+//       lane 2 also the heading sum (ref :588) — ONE loop for the three lanes;
+//   (2) lane q: sincos of step q's heading and the position increments (vx cos + vy cos(pi/2 + th)) dt (ref :586-587);
+//   (3) lanes 0, 1: the two position sums x += dx_q, y += dy_q over the round;
+//   (4) lane q: the pre-step footprint frame and the post-step robot record of step q, the Trajectory point.
+// Eight times the waves (two to eight per SIMD), the sincos of eight steps side by side.  The same operations on the same
+// values in the same order as rollout_sample (no contraction here either): bit-identical tables and cost terms
+// (tests/test_prefix_sharing_gpu.py::test_team_rollout_equals_the_thread_rollout).
+constexpr int K1A_TEAM = 8;
+__global__ void __launch_bounds__(64) sfw_rollout_team_kernel(const sfw_launch L) {
+  constexpr int TEAMS = WAVE / K1A_TEAM;
+  __shared__ double r_th[TEAMS][K1A_TEAM], r_vx[TEAMS][K1A_TEAM], r_vy[TEAMS][K1A_TEAM];  // [team][step of the round]
+  __shared__ double2 r_inc[TEAMS][K1A_TEAM];
+  __shared__ double r_px[TEAMS][K1A_TEAM + 1], r_py[TEAMS][K1A_TEAM + 1];                  // pose before step q; [nst]: after the round
+  __shared__ double r_end[TEAMS][4];
+  const int lane = threadIdx.x, g = lane / K1A_TEAM, j = lane % K1A_TEAM;
+  const int64_t local_raw = static_cast<int64_t>(blockIdx.x) * TEAMS + g;
+  const bool live = local_raw < L.chunk_count;
+  const int64_t local = live ? local_raw : L.chunk_count - 1;  // a team past the end repeats the last sample and stores nothing
+  const int64_t t = L.chunk_begin + local;
+  const int iv = static_cast<int>(t / L.nw), iw = static_cast<int>(t % L.nw);
+  const double vx_samp = L.linvels[iv], vth_samp = L.angvels[iw], vy_samp = L.vy_samp;
+  const bool scored = !(L.skip_zero_sample && vx_samp == 0.0 && vth_samp == 0.0);
+  if (live && j == 0) {
+    if (!scored) {
+      L.status[t] = SFW_ST_SKIPPED;
+      L.costs[t] = SFW_COST_SKIPPED;
+    } else {
+      L.status[t] = SFW_ST_VALID;  // the costmap scan downgrades it if a step is illegal
+    }
+    if (L.coll_step) L.coll_step[t] = -1;
+  }
+  const int S = L.S;
+  const double dt = L.dt;
+  // lanes 0, 1, 2: target, limit and running velocity of "their" recurrence; lane 2 the heading; lanes 0, 1 the position
+  const double target = j == 0 ? vx_samp : j == 1 ? vy_samp : vth_samp;  // ref :581-583
+  const double a_max = j == 0 ? L.ga.acc_x : j == 1 ? L.ga.acc_y : L.ga.acc_theta;
+  double v = j == 0 ? L.rs.vx : j == 1 ? L.rs.vy : L.rs.vtheta;
+  double th_i = L.rs.theta;
+  double p = j == 0 ? L.rs.x : L.rs.y;
+  double *const vel_out = j == 0 ? r_vx[g] : j == 1 ? r_vy[g] : r_th[g];
+  double *const pos_out = j == 0 ? r_px[g] : r_py[g];
+  for (int base = 0; base < S; base += K1A_TEAM) {
+    const int nst = min(K1A_TEAM, S - base);
+    if (j < 3) {
+      for (int q = 0; q < nst; ++q) {
+        v = new_velocity(target, v, a_max, dt);
+        vel_out[q] = j == 2 ? th_i : v;  // lane 2: the heading BEFORE this step's update (ref :586-588 integrate with the old theta)
+        th_i = th_i + v * dt;            // (meaningful on lane 2 only)
+      }
+    }
+    __syncthreads();
+    double s = 0.0, c = 0.0, vxq = 0.0, vyq = 0.0, thq = 0.0;
+    if (j < nst) {
+      thq = r_th[g][j];
+      vxq = r_vx[g][j];
+      vyq = r_vy[g][j];
+      double c2 = 0.0, s2 = 0.0;
+      sincos(thq, &s, &c);
+      if (vyq != 0.0) sincos(M_PI_2 + thq, &s2, &c2);  // holonomic term, 0 for the grid
+      r_inc[g][j] = double2{(vxq * c + vyq * c2) * dt, (vxq * s + vyq * s2) * dt};  // ref :586-587 (old theta)
+    }
+    __syncthreads();
+    if (j < 2) {
+      const double *const inc = reinterpret_cast<const double *>(r_inc[g]) + j;  // .x or .y of every increment
+      pos_out[0] = p;
+      for (int q = 0; q < nst; ++q) pos_out[q + 1] = p = p + inc[2 * q];
+    }
+    __syncthreads();
+    if (j < nst && live) {
+      const int i = base + j;
+      sfw_pose_frame f;
+      f.x = r_px[g][j]; f.y = r_py[g][j]; f.c = c; f.s = s;
+      L.frame[static_cast<int64_t>(i) * L.rstep_stride + local] = f;
+      if (L.points) {                                       // ref :578
+        double *pt = L.points + (local * S + i) * 3;
+        pt[0] = f.x;
+        pt[1] = f.y;
+        pt[2] = thq;
+      }
+      sfw_robot_step r;
+      r.x = r_px[g][j + 1]; r.y = r_py[g][j + 1]; r.vx = vxq; r.vy = vyq;
+      L.rstep[static_cast<int64_t>(i) * L.rstep_stride + local] = r;
+    }
+    // (no barrier here: the next round's phase (1) writes r_th / r_vx / r_vy, which this round read in front of its second
+    // barrier, and r_px / r_py are rewritten behind two more)
+  }
+  if (j < 3) r_end[g][j] = j == 2 ? th_i : p;  // x_S, y_S, th_S
+  if (j == 0) r_end[g][3] = v;                  // vx of the last step
+  __syncthreads();
+  if (j == 0 && live) {
+    // ref :643-666 without the costmap and social terms (left-to-right sum order kept)
+    const double dx = L.ga.wpx - r_end[g][0], dy = L.ga.wpy - r_end[g][1];
+    const double d = dx * dx + dy * dy;
+    double ang = atan2(dy, dx) - r_end[g][2];
+    ang = normalize_angle_f(static_cast<float>(ang), static_cast<float>(-M_PI), static_cast<float>(M_PI));
+    ang = fabs(ang) / M_PI;
+    const double vel = fabs(L.p.max_vel_x - r_end[g][3]) / L.p.max_vel_x;
+    L.base_cost[t] = L.p.vel_weight * vel + L.p.distance_weight * d + L.p.angle_weight * ang;
+  }
+}
+
 // K1b: footprint legality/cost of one pose, one thread per (step, sample).
 // Independent across steps once the poses are known, so the S*T checks run in
 // parallel instead of serially inside the rollout.
@@ -2332,13 +2438,18 @@ __device__ __forceinline__ sfw_sel block_reduce(sfw_sel v) {
   return v;  // valid in thread 0
 }
 
+// The cost vector's way to the host (sfw_host_mirror): stage 1 reads every cost exactly once, so it also writes it to the
+// caller-visible pinned buffer `costs_host` (nullable), and the kernel that forms the final record leaves a copy at
+// `sel_host`.  The blocking call then ends with the stream's completion instead of a device-to-host copy behind it (a blit
+// kernel and two dependency gaps: 15 us of cfg2's step, 9 us of a control cycle; profiles/r06_step_timeline_cfg2.txt).
 __global__ void __launch_bounds__(ARGMIN_BLOCK)
 sfw_argmin_stage1(const double *costs, const double *linvels, const double *angvels, int nw, int64_t T,
-                  int64_t index_base, sfw_sel *partials) {
+                  int64_t index_base, sfw_sel *partials, double *costs_host, sfw_sel *sel_host) {
   sfw_sel best = sel_empty();
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < T;
        t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     const double c = costs[t];
+    if (costs_host) costs_host[t] = c;
     if (!(c >= 0.0)) continue;
     best.n_valid += 1;
     const double lin = linvels[t / nw], ang = angvels[t % nw];
@@ -2355,14 +2466,20 @@ sfw_argmin_stage1(const double *costs, const double *linvels, const double *angv
     best.n_valid = nv;
   }
   best = block_reduce(best);
-  if (threadIdx.x == 0) partials[blockIdx.x] = best;
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = best;
+    if (sel_host) *sel_host = best;  // (single-block launch: the partial is the result)
+  }
 }
 __global__ void __launch_bounds__(ARGMIN_BLOCK)
-sfw_argmin_stage2(const sfw_sel *partials, int n, sfw_sel *out) {
+sfw_argmin_stage2(const sfw_sel *partials, int n, sfw_sel *out, sfw_sel *sel_host) {
   sfw_sel best = sel_empty();
   for (int i = threadIdx.x; i < n; i += blockDim.x) best = sel_merge(best, partials[i]);
   best = block_reduce(best);
-  if (threadIdx.x == 0) *out = best;
+  if (threadIdx.x == 0) {
+    *out = best;
+    if (sel_host) *sel_host = best;
+  }
 }
 
 // Multi-device exchange record (sfw_multi_*): row `r` of an [R,5] table = this rank's selection key
@@ -2533,6 +2650,12 @@ hipError_t sfw_launch_pair_table(uint16_t *tab, int A, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// SFW_K1A_THREADS=1 in the environment (read at every launch: tests flip it): K1a as one thread per sample
+static bool sfw_k1a_threads() {
+  const char *e = std::getenv("SFW_K1A_THREADS");
+  return e && e[0] == '1';
+}
+
 bool sfw_rollout_is_fused(const sfw_launch &L) { return L.chunk_count <= 2048 && L.S <= K1_SMALL_MAX_STEPS; }
 
 // K1a alone (pose integration + robot-step table), or the fused small-grid K1.
@@ -2543,8 +2666,14 @@ hipError_t sfw_launch_rollout_poses(const sfw_launch &L, hipStream_t stream) {
     return hipGetLastError();
   }
   const int block = 64;  // latency-bound serial rollout: spread the waves over all CUs
-  const unsigned grid = static_cast<unsigned>((L.chunk_count + block - 1) / block);
-  hipLaunchKernelGGL(sfw_rollout_kernel, dim3(grid), dim3(block), 0, stream, L);
+  if (sfw_k1a_threads()) {  // SFW_K1A_THREADS=1: round 1-5's one thread per sample (A/B and the equality test)
+    const unsigned grid = static_cast<unsigned>((L.chunk_count + block - 1) / block);
+    hipLaunchKernelGGL(sfw_rollout_kernel, dim3(grid), dim3(block), 0, stream, L);
+    return hipGetLastError();
+  }
+  constexpr int per_wave = WAVE / K1A_TEAM;
+  const unsigned grid = static_cast<unsigned>((L.chunk_count + per_wave - 1) / per_wave);
+  hipLaunchKernelGGL(sfw_rollout_team_kernel, dim3(grid), dim3(block), 0, stream, L);
   return hipGetLastError();
 }
 
@@ -2736,15 +2865,15 @@ int64_t sfw_argmin_partials(int64_t T) {
 
 hipError_t sfw_launch_argmin(const double *costs, const double *linvels, const double *angvels, int32_t nw,
                              int64_t T, int64_t index_base, sfw_sel *partials, sfw_sel *out,
-                             hipStream_t stream) {
+                             hipStream_t stream, double *costs_host, sfw_sel *sel_host) {
   const int blocks = static_cast<int>(sfw_argmin_partials(T));
   if (blocks == 1) {  // the single block's partial is the result
     hipLaunchKernelGGL(sfw_argmin_stage1, dim3(1), dim3(ARGMIN_BLOCK), 0, stream, costs, linvels, angvels, nw, T,
-                       index_base, out);
+                       index_base, out, costs_host, sel_host);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(sfw_argmin_stage1, dim3(blocks), dim3(ARGMIN_BLOCK), 0, stream, costs, linvels,
-                     angvels, nw, T, index_base, partials);
-  hipLaunchKernelGGL(sfw_argmin_stage2, dim3(1), dim3(ARGMIN_BLOCK), 0, stream, partials, blocks, out);
+                     angvels, nw, T, index_base, partials, costs_host, static_cast<sfw_sel *>(nullptr));
+  hipLaunchKernelGGL(sfw_argmin_stage2, dim3(1), dim3(ARGMIN_BLOCK), 0, stream, partials, blocks, out, sel_host);
   return hipGetLastError();
 }

@@ -220,9 +220,16 @@ class HipScorer:
     def sync(self):
         self._check(lib().sfw_grid_sync(self._h), "sfw_grid_sync")
 
-    def fetch(self, want_costs=True):
+    def fetch(self, want_costs=True, out=None):
+        """out: a caller-owned float64 buffer of nv * nw doubles the cost vector is written to (a C caller passes the same
+        array every cycle; a fresh np.empty of >= 128 KB is an mmap + page faults per call)."""
         nv, nw = self._grid
-        costs = np.empty(nv * nw, dtype=np.float64) if want_costs else None
+        if want_costs and out is not None:
+            if out.dtype != np.float64 or out.size != nv * nw or not out.flags.c_contiguous:
+                raise ValueError("fetch(out=...): need a contiguous float64 array of nv * nw elements")
+            costs = out
+        else:
+            costs = np.empty(nv * nw, dtype=np.float64) if want_costs else None
         best, key = SfwBest(), SfwBestKey()
         self._check(lib().sfw_grid_fetch(self._h, costs.ctypes.data if want_costs else None, C.byref(best),
                                          C.byref(key)), "sfw_grid_fetch")

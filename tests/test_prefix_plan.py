@@ -145,3 +145,97 @@ def test_the_plan_follows_the_device_shape(monkeypatch):
     assert part != whole and len(part[0]) >= 1
     monkeypatch.setenv("SFW_DEVICE_CUS", "not a number")
     assert _plan(*args) == whole
+
+
+def _axis(targets, v0, a_max, dt, max_p, form):
+    L = planner.lib()
+    t = np.ascontiguousarray(targets, dtype=np.float64)
+    counts = np.zeros(max_p, dtype=np.int32)
+    cls = np.full((max_p, len(t)), -1, dtype=np.int32)
+    nl, closed = C.c_int32(-1), C.c_int32(-1)
+    L.sfw_plan_axis_classes.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    rc = L.sfw_plan_axis_classes(t.ctypes.data, len(t), v0, a_max, dt, max_p, form, counts.ctypes.data, cls.ctypes.data,
+                                 C.byref(nl), C.byref(closed))
+    assert rc == 0
+    return counts[:nl.value].copy(), cls[:nl.value].copy(), bool(closed.value)
+
+
+def _classes_by_definition(targets, v0, a_max, dt, p):
+    """Partition of the targets by the bit patterns of their first p velocities (the definition, in Python)."""
+    keys = []
+    for vg in targets:
+        v, seq = v0, []
+        for _ in range(p):
+            v = _new_velocity(float(vg), v, a_max, dt)
+            seq.append(np.float64(v).tobytes())
+        keys.append(tuple(seq))
+    return keys
+
+
+def _same_partition(ids, keys):
+    seen = {}
+    for i, k in zip(ids, keys):
+        if seen.setdefault(k, i) != i:
+            return False
+    return len(set(ids)) == len(set(keys))
+
+
+def test_the_closed_form_of_an_axis_equals_the_walk_of_every_recurrence():
+    """axis_classes::build_fast (two groups that have not reached their target + one class per reached target) against the
+    generic walk (form 1) and against the definition: same class counts AND the same class of every target at every level —
+    sorted and unsorted targets, duplicates, targets exactly on the start velocity and on a value the ramp passes through,
+    start velocities inside / below / above the window, ramps that overshoot in the first step."""
+    rng = np.random.default_rng(606)
+    cases = []
+    for name in ("cfg2", "target", "cfg3"):
+        w = syn.WORKLOADS[name]
+        sc = syn.make_scene(w)
+        dt = w.sim_time / w.n_steps
+        cases.append((sc.linvels, sc.robot_state[3], sc.goal_args[0], dt, min(w.n_steps - 1, 48)))
+        cases.append((sc.angvels, sc.robot_state[5], sc.goal_args[2], dt, min(w.n_steps - 1, 48)))
+    lin, ang = syn.reference_sampler()
+    cases.append((ang, 0.1, 1.0, 0.025, 39))            # the reference's alternating angular samples: not sorted
+    cases.append((lin, 0.35, 1.0, 0.025, 39))           # start velocity ON a target
+    cases.append((np.linspace(-1, 1, 41), -0.1, 2.0, 0.025, 30))   # -0.1 + 2 x 0.05 passes through 0.0 = a target
+    cases.append((np.linspace(-1, 1, 41), 3.0, 1.0, 0.1, 48))      # start above the whole window
+    cases.append((np.linspace(-1, 1, 41), -3.0, 1.0, 0.1, 48))     # ... below it
+    cases.append((np.repeat(np.linspace(0, 1, 9), 3), 0.5, 1.0, 0.05, 20))  # duplicates never separate
+    cases.append((np.linspace(0, 1, 33), 0.5, 1e6, 0.1, 10))       # everything reached in the first step
+    for _ in range(60):
+        n = int(rng.integers(1, 90))
+        t = rng.uniform(-2, 2, n)
+        if rng.random() < 0.5:
+            t = np.round(t * 8) / 8 + 0.0                # many exact duplicates and exactly representable steps (no -0.0:
+                                                         # the next test)
+        v0 = float(rng.choice([rng.uniform(-2.5, 2.5), t[rng.integers(n)], 0.0, 0.125 * rng.integers(-16, 16)]))
+        a = float(rng.choice([0.5, 1.0, 2.5, 0.125 / 0.025]))
+        dt = float(rng.choice([0.025, 0.05, 0.25]))
+        cases.append((t, v0, a, dt, int(rng.integers(1, 49))))
+    n_closed = 0
+    for t, v0, a, dt, max_p in cases:
+        cf, clf, closed = _axis(t, v0, a, dt, max_p, 0)
+        cg, clg, closed_g = _axis(t, v0, a, dt, max_p, 1)
+        assert not closed_g
+        n_closed += closed
+        assert np.array_equal(cf, cg), (t, v0, a, dt)
+        assert np.array_equal(clf, clg), (t, v0, a, dt)     # same numbering too (both number the classes in target order)
+        for p in {1, min(2, len(cf)), len(cf) // 2 + 1, len(cf)}:
+            keys = _classes_by_definition(t, v0, a, dt, p)
+            assert cf[p - 1] == len(set(keys)) and _same_partition(clf[p - 1], keys), (p, t, v0, a, dt)
+    assert n_closed >= len(cases) - 2  # the closed form is what runs
+
+
+def test_inputs_outside_the_closed_forms_premises_take_the_walk():
+    t = np.linspace(-1, 1, 17)
+    # no acceleration: nothing moves, one class for ever
+    c, cl, closed = _axis(t, 0.3, 0.0, 0.025, 10, 0)
+    assert not closed and list(c) == [1] * 10
+    # a step below half an ulp of the start velocity: u_p = v0 for ever
+    c, cl, closed = _axis(t, 1e6, 1e-12, 0.025, 5, 0)
+    assert not closed and np.array_equal(c, _axis(t, 1e6, 1e-12, 0.025, 5, 1)[0])
+    # a negative zero among the targets (the walk compares bit patterns)
+    t2 = t.copy()
+    t2[8] = -0.0
+    c, cl, closed = _axis(t2, 0.3, 1.0, 0.025, 10, 0)
+    assert not closed and np.array_equal(cl, _axis(t2, 0.3, 1.0, 0.025, 10, 1)[1])

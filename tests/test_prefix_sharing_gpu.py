@@ -193,3 +193,29 @@ def test_results_do_not_depend_on_the_device_shape(hip_mod, monkeypatch):
             assert np.array_equal(c0, c2) and b0 == b2, (name, nv, nw, cus, xcds)
             plans.append(g2.plan_info())
         assert any(pl != plan0 for pl in plans), (plan0, plans)
+
+
+@pytest.mark.parametrize("name,nv,nw,steps", [("cfg2", 64, 64, None), ("target", 48, 47, None), ("cfg3", 50, 45, None),
+                                               ("cfg2", 47, 53, 13), ("cfg2", 46, 46, 1), ("cfg2", 46, 47, 600)])
+def test_team_rollout_equals_the_thread_rollout(hip_mod, monkeypatch, name, nv, nw, steps):
+    """K1a as teams of eight lanes per sample (sfw_rollout_team_kernel: the recurrences on three lanes, one sincos step per
+    lane, positions summed by two lanes — round 6) against one thread per sample (SFW_K1A_THREADS=1, rounds 1-5): costs,
+    sentinels, selection, Trajectory points and point counts bit for bit; step counts that are no multiple of eight, a
+    single step, 600 steps; sample counts that are no multiple of eight (the last wave's idle teams)."""
+    w = dataclasses.replace(syn.WORKLOADS[name], nv=nv, nw=nw)
+    if steps is not None:
+        w = dataclasses.replace(w, sim_time=steps * 0.025, sim_granularity=0.025)
+    scene = syn.make_scene(w)
+    assert nv * nw > 2048 and w.n_steps == (steps or w.n_steps)  # the three-kernel rollout, not the small-grid kernel
+    p = _params(w)
+    out = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("SFW_K1A_THREADS", form)
+        g = hip_mod.HipScorer(p)
+        g.load_scene(scene)
+        costs, best = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+        pts, n = g.grid_points_batch(0, nv * nw, w.n_steps)   # (> 2048 samples: the dump's K1 is the same kernel)
+        out[form] = (costs, best, pts, n)
+    assert (out["1"][0] >= 0).sum() > 0
+    assert _same(out["1"][0], out["0"][0]) and out["1"][1] == out["0"][1]
+    assert np.array_equal(out["1"][3], out["0"][3]) and _same(out["1"][2], out["0"][2])
