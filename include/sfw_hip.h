@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SFW_ABI_VERSION 1
+#define SFW_ABI_VERSION 2 /* 2 (round 6): sfw_plan_info.one_launch, sfw_plan_axis_classes */
 
 typedef enum sfw_status {
   SFW_OK = 0,
@@ -272,6 +272,17 @@ typedef struct sfw_plan_info {
   int64_t flat_samples; /* organisation = SFW_ORG_REGISTER_1 only: samples (of the first chunk's launch) that the launch
                            hands to flat-form waves running beside the register-form ones, so that every SIMD holds
                            the same number of those (0: none).  Costs do not depend on it.                      */
+  int64_t one_launch;   /* 1: a control cycle's grid (<= 1024 samples, fewer than 64 agents, flat form) — rollout,
+                           footprint checks, pedestrian simulation and selection run as ONE kernel launch.  Costs,
+                           sentinels and selection do not depend on it (SFW_CYCLE_FUSED=0 in the environment: never). */
+  int64_t rest_noise_unreproduced; /* 1: this stage holds the one configuration whose reference result is NOT reproduced
+                           (see sfw_agent.desired_velocity): a person that can never move (desired_velocity == 0) AND a
+                           robot that moves now but BRAKES TO A STOP inside the rollout of some sample (a linvel sample of
+                           0 whose deceleration ends before the horizon).  From the step the robot stands, the pair is at
+                           exact relative rest at a position the device's own pose rollout produced; lightsfm's lateral
+                           term there is the rounding noise of two atan2 on the host's libm (0 for most geometries, a
+                           full-magnitude +-1 for the others) and the kernels' is 0.  Affects those samples' social work
+                           only; 0 for every other stage, incl. the robot that stands still from the start (reproduced). */
 } sfw_plan_info;
 int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out);
 /* The plan a single-chunk stage of this grid would choose ON A WHOLE MI355X
@@ -380,6 +391,11 @@ int32_t sfw_multi_ranks(sfw_multi_handle m);
 typedef struct sfw_multi_desc {
   int32_t ranks, exchange, communicators, comm_size, rccl_version;
   int32_t devices[64], comm_devices[64];
+  /* SFW_MULTI_RCCL: the file ncclAllReduce was resolved from (dladdr) and how it was found — "SFW_RCCL_LIB" (that path in
+   * the environment, honoured first), "already mapped" (an RCCL this process had loaded — e.g. the copy torch bundles — is
+   * reused rather than a second one opened beside it) or the name the loader was given (librccl.so, librccl.so.1,
+   * /opt/rocm/lib/librccl.so).  Empty strings for SFW_MULTI_HOST_REDUCE. */
+  char rccl_path[512], rccl_found[64];
 } sfw_multi_desc;
 int sfw_multi_describe(sfw_multi_handle m, sfw_multi_desc *out);
 /* Rank r's handle (owned by m): for the single-sample calls (sfw_score_one on rank 0) and diagnostics. */

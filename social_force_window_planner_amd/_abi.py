@@ -136,12 +136,14 @@ class SfwBestKey(C.Structure):
 
 class SfwPlanInfo(C.Structure):
     _fields_ = [("split_step", C.c_int32), ("levels", C.c_int32), ("chunks", C.c_int32), ("organisation", C.c_int32),
-                ("classes", C.c_int64), ("class_steps", C.c_int64), ("samples", C.c_int64), ("flat_samples", C.c_int64)]
+                ("classes", C.c_int64), ("class_steps", C.c_int64), ("samples", C.c_int64), ("flat_samples", C.c_int64),
+                ("one_launch", C.c_int64), ("rest_noise_unreproduced", C.c_int64)]
 
     def as_dict(self):
         return {"split_step": self.split_step, "levels": self.levels, "chunks": self.chunks, "classes": self.classes,
                 "class_steps": self.class_steps, "samples": self.samples, "organisation": self.organisation,
-                "flat_samples": self.flat_samples}
+                "flat_samples": self.flat_samples, "one_launch": self.one_launch,
+                "rest_noise_unreproduced": self.rest_noise_unreproduced}
 
 
 # Every symbol include/sfw_hip.h declares (checked by tests/test_abi.py).

@@ -6,6 +6,7 @@
 #include "sfw_device.h"
 
 #include <dlfcn.h>
+#include <link.h>
 
 #include <algorithm>
 #include <chrono>
@@ -147,6 +148,8 @@ struct sfw_planner_s {
   int skip_zero = 1;
   int64_t index_base = 0;
   bool staged = false, launched = false, launched_timed = false;
+  bool launched_cycle = false;        // the last launch was the one-kernel control cycle (sfw_grid_plan_info)
+  dev_buf<unsigned> cycle_counter;    // its "blocks done" word (zero between launches)
   bool mirrored = false;              // the last launch's selection kernels left costs + record in pin_mirror (sfw_launch_argmin)
   size_t mirror_max_bytes = size_t(64) << 20;  // SFW_MIRROR_MAX_MB in the environment of sfw_create; 0: always copy
   long spin_us = 20000;               // SFW_SPIN_US in the environment of sfw_create: how long a fetch polls the stream before
@@ -351,6 +354,11 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.step_end = L.S;
   L.resume = 0;
   L.k2_form = h->k2_form;
+  L.index_base = h->index_base;
+  L.cycle_counter = h->cycle_counter.p;
+  L.sel_out = h->d_sel;
+  L.costs_host = nullptr;
+  L.sel_host = nullptr;
 }
 
 // ---- shared-prefix plan ---------------------------------------------------
@@ -687,6 +695,9 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
 
   // ---- tables: columns (chunk-independent), then rows per chunk
   std::vector<int32_t> ints;
+  ints.swap(h->cls_ints);  // (reuse the last stage's allocation)
+  ints.clear();
+  ints.reserve(static_cast<size_t>(2 * n_lv + 2) * static_cast<size_t>(h->nv + h->nw));
   auto append = [&](const std::vector<int32_t> &v) {
     const size_t o = ints.size();
     ints.insert(ints.end(), v.begin(), v.end());
@@ -700,6 +711,8 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
     ids.assign(cls.size(), -1);
     local.clear();
     rep.clear();
+    local.reserve(static_cast<size_t>(i1 - i0));  // (no growth by doubling: this runs on the blocking call's critical path)
+    rep.reserve(static_cast<size_t>(i1 - i0));
     for (int64_t i = i0; i < i1; ++i) {
       int32_t &id = ids[static_cast<size_t>(cls[static_cast<size_t>(i)])];
       if (id < 0) {
@@ -715,8 +728,10 @@ int plan_prefix(sfw_handle h, int64_t chunk, int S) {
     std::vector<axis_level> out(n_lv);
     for (size_t l = 0; l < n_lv; ++l) {
       relabel(level(cls, steps[l]), i0, i1, out[l].local, out[l].rep);
-      if (l > 0)  // classes refine: the parent of a class is the previous level's class of its representative
+      if (l > 0) {  // classes refine: the parent of a class is the previous level's class of its representative
+        out[l].src.reserve(out[l].rep.size());
         for (int32_t r : out[l].rep) out[l].src.push_back(out[l - 1].local[static_cast<size_t>(r)]);
+      }
     }
     return out;
   };
@@ -838,6 +853,12 @@ void rest_forces(const sfw_params &p, const std::vector<std::pair<int32_t, int32
 // the device's own pose rollout produced; the rounding noise at that position is not reproduced.
 bool pinned_rest_table(const sfw_params &p, const sfw_robot_state &rs, const double *pos, const sfw_agent_const *cst, int A,
                        double *out) {
+#if SFW_SIGN_OF_ZERO
+  // (round 3's A/B build: its kernels apply a sign-of-zero lateral term of their own to every pair at exact rest, at every
+  // step, which this table does not take back out — ADVICE r5.  No table there: that build is for timing comparisons.)
+  (void)p; (void)rs; (void)pos; (void)cst; (void)A; (void)out;
+  return false;
+#endif
   bool any = false;
   for (int i = 1; i < A; ++i) any |= (cst[i].desired_velocity == 0.0);
   if (!any) return false;
@@ -884,6 +905,29 @@ bool pinned_rest_table(const sfw_params &p, const sfw_robot_state &rs, const dou
 
 // Everything of a stage that depends on sfw_params: the K1->K2 tables ([S][chunk] records, chunk bounded
 // by the table budget) and the shared-prefix plan (classes of the velocity sequences under dt = sim_time/S).
+// The one configuration whose reference result the kernels do not reproduce (sfw_plan_info.rest_noise_unreproduced, DESIGN.md
+// §10): a person that can never move next to a robot that moves now and brakes to a stop inside some sample's rollout.
+// Decided from what the stage uploaded, with the device's own velocity recurrence (plain IEEE operations).
+bool rest_noise_unreproduced(sfw_handle h) {
+  if (!h->staged || h->st_A < 2 || (h->rs.vx == 0.0 && h->rs.vy == 0.0)) return false;  // (standing from the start: reproduced)
+  const sfw_agent_const *cst = reinterpret_cast<const sfw_agent_const *>(h->h_agents.data() + h->ao_cst);
+  bool pinned = false;
+  for (int i = 1; i < h->st_A && i < h->A; ++i) pinned |= (cst[i].desired_velocity == 0.0);
+  if (!pinned || h->vy_samp != 0.0) return false;
+  bool zero_row = false;
+  for (double v : h->h_lin) zero_row |= (v == 0.0);
+  if (!zero_row) return false;
+  const int S = num_steps_of(h->params);
+  const double dt = h->params.sim_time / S;
+  double vx = h->rs.vx, vy = h->rs.vy;
+  for (int i = 0; i + 1 < S; ++i) {  // at rest AFTER step i < S - 1: at least one step is integrated from the rest pose
+    vx = new_velocity_host(0.0, vx, h->ga.acc_x, dt);
+    vy = new_velocity_host(0.0, vy, h->ga.acc_y, dt);
+    if (vx == 0.0 && vy == 0.0) return true;
+  }
+  return false;
+}
+
 // Host half: chunk size under the table budget and the shared-prefix plan (class tables in h->cls_ints).  No device call.
 int64_t plan_tables_host(sfw_handle h, int *err) {
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
@@ -960,6 +1004,32 @@ int check_lds(sfw_handle h, int64_t items) {
   return SFW_OK;
 }
 
+// SFW_DEBUG_STAGE=1 in the environment: every stage / launch prints where its host time went (stderr; tuning aid)
+struct host_phases {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  std::string out;
+  explicit host_phases(const char *what) {
+    static const bool enabled = std::getenv("SFW_DEBUG_STAGE") != nullptr;
+    on = enabled;
+    if (on) {
+      out = what;
+      t = std::chrono::steady_clock::now();
+    }
+  }
+  void mark(const char *name) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    char b[64];
+    std::snprintf(b, sizeof(b), " %s %.1f", name, std::chrono::duration<double, std::micro>(n - t).count());
+    out += b;
+    t = n;
+  }
+  ~host_phases() {
+    if (on) std::fprintf(stderr, "[sfw] %s us\n", out.c_str());
+  }
+};
+
 int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int32_t nv, const double *ang,
                  int32_t nw, const sfw_goal_args *args, double vy_samp, int skip_zero, int64_t index_base,
                  bool grid = false) {
@@ -973,7 +1043,9 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     return fail(h, SFW_ERR_INVALID_ARG, "grid_stage: non-finite robot state, goal argument or sample velocity");
   if (!all_finite(lin, static_cast<size_t>(nv)) || !all_finite(ang, static_cast<size_t>(nw)))
     return fail(h, SFW_ERR_INVALID_ARG, "grid_stage: non-finite sample velocity");
+  host_phases ph("stage:");
   SFW_HIP(h, hipSetDevice(h->device));
+  ph.mark("check+setdev");
   h->h_lin.assign(lin, lin + nv);
   h->h_ang.assign(ang, ang + nw);
   h->st_K = h->K;
@@ -994,6 +1066,7 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   int plan_err = SFW_OK;
   const int64_t chunk = plan_tables_host(h, &plan_err);
   if (plan_err) return plan_err;
+  ph.mark("plan");
   {  // one arena, one copy: footprint | agents blob | linvels | angvels | relative-rest terms | pinned-rest table | class tables
     auto up16 = [](size_t b) { return (b + 15) & ~size_t(15); };
     const bool rest = !h->rest_pairs.empty();
@@ -1028,8 +1101,11 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
       pinned = pinned_rest_table(h->params, *rs, reinterpret_cast<const double *>(h->h_agents.data()),
                                  reinterpret_cast<const sfw_agent_const *>(h->h_agents.data() + h->ao_cst), h->A,
                                  reinterpret_cast<double *>(pb + o_pin));
+    ph.mark("pack");
     SFW_HIP(h, hipMemcpyAsync(h->world.p, pb, total, hipMemcpyHostToDevice, h->stream));
+    ph.mark("h2d");
     SFW_HIP(h, h->pin_world.mark(h->stream));
+    ph.mark("evrec");
     const char *db = h->world.p;
     h->d_cls_tab = h->cls_ints.empty() ? nullptr : reinterpret_cast<const int32_t *>(db + o_cls);
     h->d_pin_rest = pinned ? reinterpret_cast<const double *>(db + o_pin) : nullptr;
@@ -1064,7 +1140,9 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   SFW_HIP(h, h->costs.reserve(T + (sizeof(sfw_sel) + sizeof(double) - 1) / sizeof(double)));
   h->d_sel = reinterpret_cast<sfw_sel *>(h->costs.p + T);
   SFW_HIP(h, h->partials.reserve(sfw_argmin_partials(T)));
+  ph.mark("reserve");
   if (int e = plan_tables_device(h, chunk, grid)) return e;
+  ph.mark("tables+K1a");
   h->staged = true;
   h->launched = false;
   return SFW_OK;
@@ -1143,6 +1221,47 @@ int launch_common(sfw_handle h) {
       h->cap_S = S;
     }
   }
+  // the cost vector and the selection record reach the host through the selection kernels themselves (pinned mirror): the
+  // fetch then only waits for the stream.  Grids whose vector is larger than SFW_MIRROR_MAX_MB (default 64) keep the copy.
+  h->mirrored = false;
+  double *costs_host = nullptr;
+  sfw_sel *sel_host = nullptr;
+  if (h->mirror_max_bytes > 0 && sizeof(double) * static_cast<size_t>(T) <= h->mirror_max_bytes) {
+    const size_t cost_bytes = sizeof(double) * static_cast<size_t>(T);
+    // (growing it frees the old area: no launch still in the stream may be writing there)
+    if (cost_bytes + sizeof(sfw_sel) > h->pin_mirror.cap) SFW_HIP(h, hipStreamSynchronize(h->stream));
+    SFW_HIP(h, h->pin_mirror.reserve(cost_bytes + sizeof(sfw_sel)));
+    costs_host = reinterpret_cast<double *>(h->pin_mirror.p);
+    sel_host = reinterpret_cast<sfw_sel *>(h->pin_mirror.p + cost_bytes);
+    h->mirrored = true;
+  }
+  if (single && !prefix && !poses_done) {
+    // A control cycle's grid: K1 + K2 + K3 in ONE launch (sfw_cycle_kernel) when the launch qualifies
+    sfw_launch L;
+    fill_launch(h, L, 0, T, chunk);
+    if (h->captured) {
+      L.points = reinterpret_cast<double *>(cap_pts);
+      L.n_points = reinterpret_cast<int32_t *>(cap_n);
+      L.coll_step = reinterpret_cast<int32_t *>(cap_coll);
+      L.force_alive = 1;  // (as below)
+    }
+    L.clock_probe = timing ? h->clock.p : nullptr;
+    L.costs_host = costs_host;
+    L.sel_host = sel_host;
+    if (sfw_cycle_applies(L)) {
+      if (timing) SFW_HIP(h, hipEventRecord(h->ev[1], h->stream));  // (no K1 of its own: K1 time 0, the launch is "K2")
+      SFW_HIP(h, h->params.precision == SFW_PRECISION_F64_STRICT ? sfw_launch_cycle_strict(L, h->stream) : sfw_launch_cycle(L, h->stream));
+      if (timing) {
+        SFW_HIP(h, hipEventRecord(h->ev[2], h->stream));
+        SFW_HIP(h, hipEventRecord(h->ev[3], h->stream));
+      }
+      h->launched = true;
+      h->launched_timed = timing;
+      h->launched_cycle = true;
+      return SFW_OK;
+    }
+  }
+  h->launched_cycle = false;
   int c = 0;
   for (int64_t b = 0; b < T; b += chunk, ++c) {
     const int64_t n = (T - b < chunk) ? (T - b) : chunk;
@@ -1218,20 +1337,6 @@ int launch_common(sfw_handle h) {
     if (!single && timing) SFW_HIP(h, hipEventRecord(h->chunk_ev[3 * c + 2], h->stream));
   }
   if (timing) SFW_HIP(h, hipEventRecord(h->ev[2], h->stream));
-  // the cost vector and the selection record reach the host through the selection kernels themselves (pinned mirror): the
-  // fetch then only waits for the stream.  Grids whose vector is larger than SFW_MIRROR_MAX_MB (default 64) keep the copy.
-  h->mirrored = false;
-  double *costs_host = nullptr;
-  sfw_sel *sel_host = nullptr;
-  if (h->mirror_max_bytes > 0 && sizeof(double) * static_cast<size_t>(T) <= h->mirror_max_bytes) {
-    const size_t cost_bytes = sizeof(double) * static_cast<size_t>(T);
-    // (growing it frees the old area: no launch still in the stream may be writing there)
-    if (cost_bytes + sizeof(sfw_sel) > h->pin_mirror.cap) SFW_HIP(h, hipStreamSynchronize(h->stream));
-    SFW_HIP(h, h->pin_mirror.reserve(cost_bytes + sizeof(sfw_sel)));
-    costs_host = reinterpret_cast<double *>(h->pin_mirror.p);
-    sel_host = reinterpret_cast<sfw_sel *>(h->pin_mirror.p + cost_bytes);
-    h->mirrored = true;
-  }
   SFW_HIP(h, sfw_launch_argmin(h->costs.p, h->d_linvels, h->d_angvels, h->nw, T, h->index_base,
                                h->partials.p, h->d_sel, h->stream, costs_host, sel_host));
   if (timing) SFW_HIP(h, hipEventRecord(h->ev[3], h->stream));
@@ -1308,6 +1413,15 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SFW_ERR_NO_DEVICE;
   if (device < 0 || device >= count) return SFW_ERR_INVALID_ARG;
+#ifdef SFW_ABLATION_BUILD
+  {  // results wrong by construction (sfw_device.h): only a timing script that says so gets a handle
+    const char *ok = std::getenv("SFW_ALLOW_ABLATION");
+    if (!ok || ok[0] != '1') {
+      std::fprintf(stderr, "[sfw] this libsfw_hip.so is an ABLATION build (results wrong by construction); set SFW_ALLOW_ABLATION=1 to time it\n");
+      return SFW_ERR_UNSUPPORTED;
+    }
+  }
+#endif
   sfw_handle h = new (std::nothrow) sfw_planner_s();
   if (!h) return SFW_ERR_HIP;
   h->params = *params;
@@ -1360,6 +1474,8 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->split.join, hipEventDisableTiming);
   if (e == hipSuccess) h->split.side = h->side;
   for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
+  if (e == hipSuccess) e = h->cycle_counter.reserve(1);
+  if (e == hipSuccess) e = hipMemsetAsync(h->cycle_counter.p, 0, sizeof(unsigned), h->stream);
   if (e != hipSuccess) {
     sfw_destroy(h);
     return SFW_ERR_HIP;
@@ -1385,6 +1501,7 @@ int sfw_destroy(sfw_handle h) {
   h->fcode.release();
   h->partials.release();
   h->clock.release();
+  h->cycle_counter.release();
   h->cap.release();
   h->pin_cap.release();
   h->points.release();
@@ -1715,6 +1832,13 @@ int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out) {
   }
   out->organisation = sfw_social_organisation(h->st_A, out->chunks > 0 ? (T + out->chunks - 1) / out->chunks : T, h->st_O, h->k2_form, h->n_cu);
   out->flat_samples = sfw_social_flat_items(h->st_A, h->st_O, h->st_NG, out->chunks > 0 ? (T + out->chunks - 1) / out->chunks : T, h->k2_form, h->n_cu);
+  out->rest_noise_unreproduced = rest_noise_unreproduced(h) ? 1 : 0;
+  out->one_launch = 0;
+  if (out->chunks == 1 && h->prefix_steps.empty()) {
+    sfw_launch L;
+    fill_launch(h, L, 0, T, T);
+    out->one_launch = sfw_cycle_applies(L) ? 1 : 0;
+  }
   return SFW_OK;
 }
 
@@ -1915,11 +2039,47 @@ struct rccl_api {
   ncclResult_t (*GetVersion)(int *) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+  std::string path;      // the file ncclAllReduce really came from (dladdr)
+  std::string how;       // "SFW_RCCL_LIB", "already mapped", or the name dlopen was given
+  // Which RCCL?  (1) SFW_RCCL_LIB in the environment: that file, or an error — never a silent fall-through; (2) an RCCL
+  // this process has mapped already (a Python process that imported torch holds torch's bundled copy: a second RCCL beside
+  // it would mean two sets of communicator state in one process) — found by walking the loaded objects, reopened with
+  // RTLD_NOLOAD; (3) the loader's search: librccl.so, librccl.so.1, /opt/rocm/lib/librccl.so.
   void load_once() {
-    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (lib) break;
+    if (const char *forced = std::getenv("SFW_RCCL_LIB")) {
+      if (forced[0]) {
+        lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) {
+          error = std::string("SFW_RCCL_LIB=") + forced + ": " + dlerror();
+          return;
+        }
+        how = "SFW_RCCL_LIB";
+      }
     }
+    if (!lib) {
+      std::string mapped;
+      dl_iterate_phdr(
+          [](struct dl_phdr_info *info, size_t, void *out) {
+            if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl.so")) {
+              *static_cast<std::string *>(out) = info->dlpi_name;
+              return 1;
+            }
+            return 0;
+          },
+          &mapped);
+      if (!mapped.empty()) {
+        lib = dlopen(mapped.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+        if (lib) how = "already mapped";
+      }
+    }
+    if (!lib)
+      for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (lib) {
+          how = name;
+          break;
+        }
+      }
     if (!lib) {
       error = std::string("cannot load librccl.so: ") + dlerror();
       return;
@@ -1938,7 +2098,10 @@ struct rccl_api {
       dlclose(lib);
       lib = nullptr;
       error = "librccl.so lacks ncclCommInitAll/ncclAllReduce/ncclGroupStart/...";
+      return;
     }
+    Dl_info di;
+    if (dladdr(reinterpret_cast<void *>(AllReduce), &di) && di.dli_fname) path = di.dli_fname;
   }
   // "" or why RCCL is not available; safe from several threads (two planners created concurrently)
   const std::string &load() {
@@ -1948,6 +2111,7 @@ struct rccl_api {
   std::once_flag once;
 };
 rccl_api g_rccl;
+thread_local std::string g_multi_create_error;
 
 // One worker thread per rank of a multi handle, alive for the handle's lifetime: a rank's stage + launch is ~100 us
 // of host work (shared-prefix planning, one H2D copy, a dozen kernel launches) and the ranks are independent, so a
@@ -2092,13 +2256,16 @@ int sfw_multi_create(const sfw_params *params, const int *devices, int32_t R, in
   if (rc == SFW_OK && hipHostMalloc(reinterpret_cast<void **>(&m->pin_table), sizeof(double) * 5 * R, hipHostMallocDefault) != hipSuccess)
     rc = SFW_ERR_HIP;
   if (rc == SFW_OK && exchange == SFW_MULTI_RCCL) {
-    if (!g_rccl.load().empty()) rc = SFW_ERR_UNSUPPORTED;
-    else {
+    if (!g_rccl.load().empty()) {
+      rc = SFW_ERR_UNSUPPORTED;
+      g_multi_create_error = g_rccl.load();
+    } else {
       m->comm.assign(static_cast<size_t>(R), nullptr);
       const ncclResult_t nr = g_rccl.CommInitAll(m->comm.data(), R, devices);
       if (nr != ncclSuccess) {
         m->comm.clear();
         rc = SFW_ERR_HIP;
+        g_multi_create_error = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(nr) + " (" + g_rccl.path + ")";
       }
     }
   }
@@ -2128,7 +2295,11 @@ int sfw_multi_destroy(sfw_multi_handle m) {
   return SFW_OK;
 }
 
-const char *sfw_multi_last_error(sfw_multi_handle m) { return m ? m->err.c_str() : "null handle"; }
+// (a NULL handle: why this thread's last sfw_multi_create failed, when it said why — RCCL could not be resolved or initialised)
+const char *sfw_multi_last_error(sfw_multi_handle m) {
+  if (m) return m->err.c_str();
+  return g_multi_create_error.empty() ? "null handle" : g_multi_create_error.c_str();
+}
 int32_t sfw_multi_ranks(sfw_multi_handle m) { return m ? m->R : 0; }
 int sfw_multi_describe(sfw_multi_handle m, sfw_multi_desc *out) {
   if (!m || !out) return SFW_ERR_INVALID_ARG;
@@ -2140,6 +2311,8 @@ int sfw_multi_describe(sfw_multi_handle m, sfw_multi_desc *out) {
   out->comm_size = -1;
   if (m->exchange == SFW_MULTI_RCCL) {
     if (g_rccl.GetVersion) (void)g_rccl.GetVersion(&out->rccl_version);
+    std::snprintf(out->rccl_path, sizeof(out->rccl_path), "%s", g_rccl.path.c_str());
+    std::snprintf(out->rccl_found, sizeof(out->rccl_found), "%s", g_rccl.how.c_str());
     for (size_t r = 0; r < m->comm.size() && r < 64; ++r)
       if (m->comm[r]) {
         out->communicators += 1;

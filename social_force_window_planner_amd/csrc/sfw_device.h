@@ -18,6 +18,15 @@
 #define SFW_SIGN_OF_ZERO 0
 #endif
 
+// Ablation builds (make EXTRA=-DSFW_ABL_...: a part of a kernel taken out to price it) produce results that are wrong by
+// construction.  Any of those macros marks the whole library: sfw_create refuses to make a handle unless SFW_ALLOW_ABLATION=1
+// is in the environment (the timing scripts under tools/ set it; no test and no bench run does).
+#if defined(SFW_ABL_NOROBOT) || defined(SFW_ABL_NOREAD) || defined(SFW_ABL_NOMATH) || defined(SFW_ABL_NOATOM) ||        \
+    defined(SFW_ABL_NOAGENT) || defined(SFW_ABL_KEEPALIVE) || defined(SFW_ABL_HALF_LDS) || defined(SFW_ABL_NOOBSLOOP) || \
+    defined(SFW_ABL_NOREDUCE)
+#define SFW_ABLATION_BUILD 1
+#endif
+
 // Device shape the launch heuristics default to (a whole MI355X: 256 compute units in 8 XCDs of 32); a handle reads its
 // device's own (hipDeviceProp_t.multiProcessorCount) and carries it into every launch (sfw_launch.n_cu / n_xcd).
 #define SFW_DEFAULT_CUS 256
@@ -80,6 +89,15 @@ struct sfw_cls_agent {
 };
 enum { SFW_PHASE_WHOLE = 0, SFW_PHASE_PREFIX = 1, SFW_PHASE_SUFFIX = 2 };
 
+// Selection record (see sfw_best / sfw_best_key in the public header).
+struct sfw_sel {
+  double cost;       // +inf when nothing selectable
+  double neg_linvel;
+  double abs_angvel;
+  long long neg_index;  // -(global iteration index)
+  long long n_valid;
+};
+
 // Everything the kernels need that is uniform over a launch.
 struct sfw_launch {
   // scoring parameters
@@ -112,8 +130,9 @@ struct sfw_launch {
                                    // handed-over state, evaluated on the host (sfw_capi.hip rest_forces)
   const double *pin_rest;          // 4 + A doubles or null: a person that can never move next to a robot that stands still for
                                    // the whole rollout is at exact relative rest at EVERY step; {robot x, y, lateral force on
-                                   // the robot (x, y), Wp per person or -1} evaluated on the host (sfw_capi.hip
-                                   // pinned_rest_table) for the steps whose robot record is (x, y) at velocity 0
+                                   // the robot (x, y), Wp correction per person — 0 when the person is not pinned —} evaluated
+                                   // on the host (sfw_capi.hip pinned_rest_table) for the steps whose robot record is (x, y)
+                                   // at velocity 0; the kernels add entry 4 + i to person i's social work unconditionally
   int32_t A;
   const double *obstacles;         // O x (x,y)
   int32_t O;
@@ -165,16 +184,14 @@ struct sfw_launch {
   // measurement only (sfw_set_timing): the middle block of a K2 launch leaves {s_memtime, s_memrealtime} at its start in [0..1]
   // and at its end in [2..3]; their ratio is the shader clock the kernel really ran at.  Nullable.
   unsigned long long *clock_probe;
+  // one launch per control cycle (sfw_cycle_kernel): the selection's inputs and outputs ride with the scoring launch
+  int64_t index_base;       // global iteration index of sample 0 (sfw_grid_stage)
+  unsigned *cycle_counter;  // one word, zero between launches: blocks that have written their cost
+  sfw_sel *sel_out;         // the selection record (device)
+  double *costs_host;       // nullable: pinned mirror of the cost vector ...
+  sfw_sel *sel_host;        // ... and of the record
 };
 
-// Selection record (see sfw_best / sfw_best_key in the public header).
-struct sfw_sel {
-  double cost;       // +inf when nothing selectable
-  double neg_linvel;
-  double abs_angvel;
-  long long neg_index;  // -(global iteration index)
-  long long n_valid;
-};
 
 // Fills L.k from L.p and L.O (host).
 void sfw_derive(sfw_launch &L);
@@ -192,11 +209,16 @@ struct sfw_split_streams {
   hipEvent_t fork, join;
 };
 hipError_t sfw_launch_social(const sfw_launch &L, hipStream_t stream, const sfw_split_streams *sp = nullptr);
+// K1 + K2 + K3 of a small grid in ONE launch (sfw_kernels.hip sfw_cycle_kernel); sfw_cycle_applies says whether a launch
+// qualifies (L.cycle_counter / sel_out / index_base set; costs_host / sel_host optional)
+bool sfw_cycle_applies(const sfw_launch &L);
+hipError_t sfw_launch_cycle(const sfw_launch &L, hipStream_t stream);
 #ifndef SFW_STRICT_BUILD
 // the same launcher over the K2 kernels compiled with the longer polynomials (sfw_kernels_strict.hip): SFW_PRECISION_F64_STRICT
 // samples of a launch over T samples that the register form hands to flat-form waves (0: none)
 int64_t sfw_social_flat_items(int A, int O, int NG, int64_t T, int form, int cus);
 hipError_t sfw_launch_social_strict(const sfw_launch &L, hipStream_t stream, const sfw_split_streams *sp = nullptr);
+hipError_t sfw_launch_cycle_strict(const sfw_launch &L, hipStream_t stream);
 #endif
 // true when sfw_launch_rollout_poses runs all of K1 in one launch (small grids): the only form that writes L.points
 bool sfw_rollout_is_fused(const sfw_launch &L);

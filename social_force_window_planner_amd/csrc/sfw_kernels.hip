@@ -226,19 +226,23 @@ __device__ __forceinline__ bool scan_code(double fc, double &cm, int &n_ok) {
   ++n_ok;
   return true;
 }
-__device__ __forceinline__ void scan_finish(const sfw_launch &L, int64_t t, int64_t local, double cm, int n_ok) {
+// Returns whether every pose was legal; *base_out (nullable) receives the pedestrian-free cost of a legal trajectory.
+__device__ __forceinline__ bool scan_finish(const sfw_launch &L, int64_t t, int64_t local, double cm, int n_ok,
+                                            double *base_out = nullptr) {
   const int S = L.S;
   if (L.n_points) L.n_points[local] = n_ok;
   if (n_ok < S) {
     L.status[t] = SFW_ST_INVALID;
     L.costs[t] = SFW_COST_INVALID;
-    return;
+    return false;
   }
   cm = cm / S;
   const double base = L.base_cost[t] + L.p.costmap_weight * cm;
   L.base_cost[t] = base;
+  if (base_out) *base_out = base;
   // No agent vector at all: social work is identically 0 and K2 is not launched.
   if (L.A == 0) L.costs[t] = base + L.p.social_weight * 0.0;
+  return true;
 }
 
 // K1a: one thread per sample.
@@ -420,164 +424,214 @@ __device__ __forceinline__ int footprint_edge(const sfw_launch &L, double x, dou
 //   (5) one (pose, footprint edge) per lane, combined per pose with an LDS max; (6) lane 0 scans the codes in step order.
 // The same operations on the same values in the same order as the one-thread-per-sample K1a + K1b + K1c (no
 // contraction here either): bit-identical poses, cells, codes and costs.
+// The phases are functions of (thread index, thread count) over one sample's LDS arrays (k1s_lds): sfw_rollout_small_kernel
+// runs them with its 256 threads and a block barrier between them; sfw_cycle_kernel (below, behind K2) spreads them over
+// its waves — the recurrences on one wave while another stages the pedestrians, the footprint tasks beside the pedestrian
+// rollout.
 constexpr int K1_SMALL_MAX_STEPS = 512;
 constexpr int K1_SMALL_BLOCK = 256;  // four waves per sample: the (pose, edge) footprint tasks are the bulk of the work
-__global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const sfw_launch L) {
-  __shared__ double th[K1_SMALL_MAX_STEPS], vxs[K1_SMALL_MAX_STEPS], vys[K1_SMALL_MAX_STEPS];
-  __shared__ double2 cs[K1_SMALL_MAX_STEPS], dxy[K1_SMALL_MAX_STEPS];
-  __shared__ double xs[K1_SMALL_MAX_STEPS + 1], ys[K1_SMALL_MAX_STEPS + 1];
-  __shared__ int code[K1_SMALL_MAX_STEPS];
-  __shared__ double quot[K1_SMALL_MAX_STEPS];  // code / 255.0 of every step (ref :575), formed across the lanes
-  __shared__ double th_end;
-  const int64_t local = blockIdx.x;
-  const int64_t t = L.chunk_begin + local;
-  const int S = L.S;
-  const int iv = static_cast<int>(t / L.nw), iw = static_cast<int>(t % L.nw);
-  const double vx_samp = L.linvels[iv], vth_samp = L.angvels[iw], vy_samp = L.vy_samp;
-  const bool scored = !(L.skip_zero_sample && vx_samp == 0.0 && vth_samp == 0.0);
+struct k1s_lds {
+  double *th, *vxs, *vys;  // [S] heading before step i, velocities after it
+  double2 *cs, *dxy;       // [S] cos / sin of the heading, position increments
+  double *xs, *ys;         // [S + 1] pose before step i; [S]: the final pose
+  int *code;               // [S] footprint code of pose i (maximum over its edges)
+  double *quot;            // [S] code / 255.0 (ref :575), formed across the lanes
+  double *th_end;          // [1]
+  // carved out of `base` (16-byte aligned) for S steps; base = nullptr sizes the allocation
+  __host__ __device__ k1s_lds(char *base, int S, size_t *bytes = nullptr) {
+    char *const base0 = base;
+    auto take = [&](size_t n) {
+      char *p = base;
+      base += (n + 15) & ~size_t(15);
+      return p;
+    };
+    const size_t n = static_cast<size_t>(S);
+    th = reinterpret_cast<double *>(take(8 * n));
+    vxs = reinterpret_cast<double *>(take(8 * n));
+    vys = reinterpret_cast<double *>(take(8 * n));
+    cs = reinterpret_cast<double2 *>(take(16 * n));
+    dxy = reinterpret_cast<double2 *>(take(16 * n));
+    xs = reinterpret_cast<double *>(take(8 * (n + 1)));
+    ys = reinterpret_cast<double *>(take(8 * (n + 1)));
+    code = reinterpret_cast<int *>(take(4 * n));
+    quot = reinterpret_cast<double *>(take(8 * n));
+    th_end = reinterpret_cast<double *>(take(8));
+    if (bytes) *bytes = static_cast<size_t>(base - base0);
+  }
+};
+struct k1s_sample {
+  int64_t local, t;
+  double vx_samp, vy_samp, vth_samp;
+  bool scored;
+};
+__device__ __forceinline__ k1s_sample k1s_sample_of(const sfw_launch &L, int64_t local) {
+  k1s_sample q;
+  q.local = local;
+  q.t = L.chunk_begin + local;
+  const int iv = static_cast<int>(q.t / L.nw), iw = static_cast<int>(q.t % L.nw);
+  q.vx_samp = L.linvels[iv];
+  q.vth_samp = L.angvels[iw];
+  q.vy_samp = L.vy_samp;
+  q.scored = !(L.skip_zero_sample && q.vx_samp == 0.0 && q.vth_samp == 0.0);
+  return q;
+}
+// the sample's status words (one thread)
+__device__ __forceinline__ void k1s_head(const sfw_launch &L, const k1s_sample &q) {
+  if (!q.scored) {
+    L.status[q.t] = SFW_ST_SKIPPED;
+    L.costs[q.t] = SFW_COST_SKIPPED;
+  } else {
+    L.status[q.t] = SFW_ST_VALID;  // the costmap scan downgrades it if a step is illegal
+  }
+  if (L.coll_step) L.coll_step[q.t] = -1;
+}
+// (1) velocities and headings: threads 0, 1, 2 walk ONE loop, each with its own target, velocity and limit (as three
+// branches of an if the wave ran the three recurrences one after the other); thread 2 also sums the heading
+__device__ __forceinline__ void k1s_velocities(const sfw_launch &L, const k1s_lds &a, const k1s_sample &q, int S, int tid) {
+  if (tid >= 3) return;
   const double dt = L.dt;
-  const int tid = threadIdx.x;
-  // (1) velocities and headings: lanes 0, 1, 2 walk ONE loop, each with its own target, velocity and limit (as three
-  // branches of an if the wave ran the three recurrences one after the other); lane 2 also sums the heading
-  if (tid == 0) {
-    if (!scored) {
-      L.status[t] = SFW_ST_SKIPPED;
-      L.costs[t] = SFW_COST_SKIPPED;
-    } else {
-      L.status[t] = SFW_ST_VALID;  // the costmap scan downgrades it if a step is illegal
-    }
-    if (L.coll_step) L.coll_step[t] = -1;
+  const double target = tid == 0 ? q.vx_samp : tid == 1 ? q.vy_samp : q.vth_samp;  // ref :581-583
+  const double a_max = tid == 0 ? L.ga.acc_x : tid == 1 ? L.ga.acc_y : L.ga.acc_theta;
+  double v = tid == 0 ? L.rs.vx : tid == 1 ? L.rs.vy : L.rs.vtheta;
+  double th_i = L.rs.theta;
+  double *const out = tid == 0 ? a.vxs : tid == 1 ? a.vys : a.th;
+  for (int i = 0; i < S; ++i) {
+    v = new_velocity(target, v, a_max, dt);
+    // threads 0, 1: the new velocity; thread 2: the heading BEFORE this step's update (ref :586-588 integrate with the old theta)
+    out[i] = tid == 2 ? th_i : v;
+    th_i = th_i + v * dt;  // (meaningful on thread 2 only)
   }
-  if (tid < 3) {
-    const double target = tid == 0 ? vx_samp : tid == 1 ? vy_samp : vth_samp;      // ref :581-583
-    const double a_max = tid == 0 ? L.ga.acc_x : tid == 1 ? L.ga.acc_y : L.ga.acc_theta;
-    double v = tid == 0 ? L.rs.vx : tid == 1 ? L.rs.vy : L.rs.vtheta;
-    double th_i = L.rs.theta;
-    double *const out = tid == 0 ? vxs : tid == 1 ? vys : th;
-#if defined(SFW_K1S_ABL) && SFW_K1S_ABL == 4
-    for (int i = 0; i < S; ++i) out[i] = tid == 2 ? th_i + 0.01 * i : v;
-    for (int i = 0; i < 0; ++i) {
-#else
-    for (int i = 0; i < S; ++i) {
-#endif
-      v = new_velocity(target, v, a_max, dt);
-      // lanes 0, 1: the new velocity; lane 2: the heading BEFORE this step's update (ref :586-588 integrate with the old theta)
-      out[i] = tid == 2 ? th_i : v;
-      th_i = th_i + v * dt;  // (meaningful on lane 2 only)
-    }
-    if (tid == 2) th_end = th_i;
-  }
-  __syncthreads();
-  // (2) sines and position increments, one step per lane
-  for (int i = tid; i < S; i += blockDim.x) {
+  if (tid == 2) *a.th_end = th_i;
+}
+// (2) sines and position increments, one step per thread
+__device__ __forceinline__ void k1s_increments(const sfw_launch &L, const k1s_lds &a, int S, int tid, int nthr) {
+  const double dt = L.dt;
+  for (int i = tid; i < S; i += nthr) {
     double s, c, c2 = 0.0, s2 = 0.0;
-#if defined(SFW_K1S_ABL) && SFW_K1S_ABL == 2  // (ablation builds of tools/k1small_ablation.sh: times only, results wrong)
-    s = th[i]; c = 1.0 - th[i];
-#else
-    sincos(th[i], &s, &c);
-#endif
-    if (vys[i] != 0.0) sincos(M_PI_2 + th[i], &s2, &c2);  // holonomic term, 0 for the grid
-    cs[i] = double2{c, s};
-    dxy[i] = double2{(vxs[i] * c + vys[i] * c2) * dt, (vxs[i] * s + vys[i] * s2) * dt};  // ref :586-587
-    code[i] = 0;
+    sincos(a.th[i], &s, &c);
+    if (a.vys[i] != 0.0) sincos(M_PI_2 + a.th[i], &s2, &c2);  // holonomic term, 0 for the grid
+    a.cs[i] = double2{c, s};
+    a.dxy[i] = double2{(a.vxs[i] * c + a.vys[i] * c2) * dt, (a.vxs[i] * s + a.vys[i] * s2) * dt};  // ref :586-587
+    a.code[i] = 0;
   }
-  __syncthreads();
-  // (3) positions: xs[i] = pose before step i, xs[S] = final pose
-  // (lanes 0 and 1 in ONE loop, as above)
-  if (tid < 2) {
-    double p = tid == 0 ? L.rs.x : L.rs.y;
-    double *const out = tid == 0 ? xs : ys;
-    const double *const inc = reinterpret_cast<const double *>(dxy) + tid;  // .x or .y of every increment
-    out[0] = p;
-    for (int i = 0; i < S; ++i) out[i + 1] = p = p + inc[2 * i];
-  }
-  __syncthreads();
-  // (4) records, one step per lane
-  for (int i = tid; i < S; i += blockDim.x) {
-    if (L.points) {                                        // ref :578
-      double *pt = L.points + (local * S + i) * 3;
-      pt[0] = xs[i];
-      pt[1] = ys[i];
-      pt[2] = th[i];
+}
+// (3) positions: xs[i] = pose before step i, xs[S] = final pose (threads 0 and 1 in ONE loop, as above)
+__device__ __forceinline__ void k1s_positions(const sfw_launch &L, const k1s_lds &a, int S, int tid) {
+  if (tid >= 2) return;
+  double p = tid == 0 ? L.rs.x : L.rs.y;
+  double *const out = tid == 0 ? a.xs : a.ys;
+  const double *const inc = reinterpret_cast<const double *>(a.dxy) + tid;  // .x or .y of every increment
+  out[0] = p;
+  for (int i = 0; i < S; ++i) out[i + 1] = p = p + inc[2 * i];
+}
+// (4) records, one step per thread: Trajectory points (ref :578) and — for a K2 that reads them from memory — the robot steps
+template <bool TABLE>
+__device__ __forceinline__ void k1s_records(const sfw_launch &L, const k1s_lds &a, const k1s_sample &q, int S, int tid, int nthr) {
+  for (int i = tid; i < S; i += nthr) {
+    if (L.points) {
+      double *pt = L.points + (q.local * S + i) * 3;
+      pt[0] = a.xs[i];
+      pt[1] = a.ys[i];
+      pt[2] = a.th[i];
     }
-    sfw_robot_step r;
-    r.x = xs[i + 1]; r.y = ys[i + 1]; r.vx = vxs[i]; r.vy = vys[i];
-    L.rstep[static_cast<int64_t>(i) * L.rstep_stride + local] = r;
+    if constexpr (TABLE) {
+      sfw_robot_step r;
+      r.x = a.xs[i + 1]; r.y = a.ys[i + 1]; r.vx = a.vxs[i]; r.vy = a.vys[i];
+      L.rstep[static_cast<int64_t>(i) * L.rstep_stride + q.local] = r;
+    }
   }
-  if (tid == 0) {
-    // ref :643-666 without the costmap and social terms (left-to-right sum order kept)
-    const double dx = L.ga.wpx - xs[S], dy = L.ga.wpy - ys[S];
-    const double d = dx * dx + dy * dy;
-#if defined(SFW_K1S_ABL) && SFW_K1S_ABL == 3
-    double ang = dy - dx - th_end;
-#else
-    double ang = atan2(dy, dx) - th_end;
-#endif
-    ang = normalize_angle_f(static_cast<float>(ang), static_cast<float>(-M_PI), static_cast<float>(M_PI));
-    ang = fabs(ang) / M_PI;
-    const double vel = fabs(L.p.max_vel_x - vxs[S - 1]) / L.p.max_vel_x;
-    L.base_cost[t] = L.p.vel_weight * vel + L.p.distance_weight * d + L.p.angle_weight * ang;
-  }
-  if (!scored) {
-    if (tid == 0 && L.n_points) L.n_points[local] = 0;
-    return;
-  }
-  // (5) footprint: the pose centre must be on the map (ref :545, src/costmap_model.cpp:36-37); K < 3: centre cell
-  // only; else every (pose, edge) is a task of its own and a pose's code is the maximum over its tasks
+}
+// ... and the pedestrian-free cost terms (one thread): ref :643-666 without the costmap and social terms (left-to-right sum order kept)
+__device__ __forceinline__ void k1s_base_cost(const sfw_launch &L, const k1s_lds &a, const k1s_sample &q, int S) {
+  const double dx = L.ga.wpx - a.xs[S], dy = L.ga.wpy - a.ys[S];
+  const double d = dx * dx + dy * dy;
+  double ang = atan2(dy, dx) - *a.th_end;
+  ang = normalize_angle_f(static_cast<float>(ang), static_cast<float>(-M_PI), static_cast<float>(M_PI));
+  ang = fabs(ang) / M_PI;
+  const double vel = fabs(L.p.max_vel_x - a.vxs[S - 1]) / L.p.max_vel_x;
+  L.base_cost[q.t] = L.p.vel_weight * vel + L.p.distance_weight * d + L.p.angle_weight * ang;
+}
+// (5) footprint: the pose centre must be on the map (ref :545, src/costmap_model.cpp:36-37); K < 3: centre cell
+// only; else every (pose, edge) is a task of its own and a pose's code is the maximum over its tasks
+__device__ __forceinline__ void k1s_footprint(const sfw_launch &L, const k1s_lds &a, int S, int tid, int nthr) {
   const int K = L.K;
   if (K < 3) {
-    for (int i = tid; i < S; i += blockDim.x) {
-      const double2 a = cs[i];
-      const double fc = footprint_cost(L, xs[i], ys[i], a.x, a.y);
-      code[i] = fc < 0 ? FOOT_OFFMAP : static_cast<int>(fc);
+    for (int i = tid; i < S; i += nthr) {
+      const double2 cs = a.cs[i];
+      const double fc = footprint_cost(L, a.xs[i], a.ys[i], cs.x, cs.y);
+      a.code[i] = fc < 0 ? FOOT_OFFMAP : static_cast<int>(fc);
     }
-  } else {
-    const double inv_res = 1.0 / L.resolution;
-#if defined(SFW_K1S_ABL) && SFW_K1S_ABL == 1
-    for (int task = tid; task < 0; task += blockDim.x) {
-#else
-    for (int task = tid; task < S * K; task += blockDim.x) {
-#endif
-      const int i = task / K, e = task - i * K;
-      const double2 a = cs[i];
-      int v = footprint_edge(L, xs[i], ys[i], a.x, a.y, e);
-      if (e == 0) {
-        unsigned cx, cy;
-        if (!world_to_map(L, inv_res, xs[i], ys[i], cx, cy)) v = FOOT_OFFMAP;
-      }
-      atomicMax(&code[i], v);
-    }
+    return;
   }
-  __syncthreads();
-  // (6) in-order scan (scan_code, K1c): the first illegal step rejects, else the sum of code / 255.0 in step order.  The
-  // divisions — ~15 dependent instructions each — are formed one step per lane; lane 0 only adds, eight quotients at a time
-  for (int i = tid; i < S; i += blockDim.x) quot[i] = static_cast<double>(code[i]) / 255.0;
-  __syncthreads();
-  if (tid == 0) {
-    double cm = 0.0;
-    int n_ok = 0;
-    bool stopped = false;
-    for (int base = 0; base < S && !stopped; base += 8) {
-      int c[8];
-      double q[8];
+  const double inv_res = 1.0 / L.resolution;
+  for (int task = tid; task < S * K; task += nthr) {
+    const int i = task / K, e = task - i * K;
+    const double2 cs = a.cs[i];
+    int v = footprint_edge(L, a.xs[i], a.ys[i], cs.x, cs.y, e);
+    if (e == 0) {
+      unsigned cx, cy;
+      if (!world_to_map(L, inv_res, a.xs[i], a.ys[i], cx, cy)) v = FOOT_OFFMAP;
+    }
+    atomicMax(&a.code[i], v);
+  }
+}
+// (6) in-order scan (scan_code, K1c): the first illegal step rejects, else the sum of code / 255.0 in step order.  The
+// divisions — ~15 dependent instructions each — are formed one step per thread; one thread only adds, eight quotients at a time
+__device__ __forceinline__ void k1s_quotients(const k1s_lds &a, int S, int tid, int nthr) {
+  for (int i = tid; i < S; i += nthr) a.quot[i] = static_cast<double>(a.code[i]) / 255.0;
+}
+__device__ __forceinline__ bool k1s_scan(const sfw_launch &L, const k1s_lds &a, const k1s_sample &q, int S, double *base_out = nullptr) {
+  double cm = 0.0;
+  int n_ok = 0;
+  bool stopped = false;
+  for (int base = 0; base < S && !stopped; base += 8) {
+    int c[8];
+    double qt[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        c[j] = code[min(base + j, S - 1)];
-        q[j] = quot[min(base + j, S - 1)];
-      }
+    for (int j = 0; j < 8; ++j) {
+      c[j] = a.code[min(base + j, S - 1)];
+      qt[j] = a.quot[min(base + j, S - 1)];
+    }
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (!stopped && base + j < S) {
-          if (c[j] >= 254 || c[j] < 0) {
-            stopped = true;
-          } else {
-            cm += q[j];
-            ++n_ok;
-          }
+    for (int j = 0; j < 8; ++j)
+      if (!stopped && base + j < S) {
+        if (c[j] >= 254 || c[j] < 0) {
+          stopped = true;
+        } else {
+          cm += qt[j];
+          ++n_ok;
         }
-    }
-    scan_finish(L, t, local, cm, n_ok);
+      }
   }
+  return scan_finish(L, q.t, q.local, cm, n_ok, base_out);
+}
+
+__global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const sfw_launch L) {
+  __shared__ __attribute__((aligned(16))) char k1s_area[8 * K1_SMALL_MAX_STEPS * 3 + 16 * K1_SMALL_MAX_STEPS * 2 +
+                                                        8 * (K1_SMALL_MAX_STEPS + 2) * 2 + 4 * K1_SMALL_MAX_STEPS +
+                                                        8 * K1_SMALL_MAX_STEPS + 16];
+  const int S = L.S;
+  const k1s_lds a(k1s_area, K1_SMALL_MAX_STEPS);
+  const k1s_sample q = k1s_sample_of(L, blockIdx.x);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if (tid == 0) k1s_head(L, q);
+  k1s_velocities(L, a, q, S, tid);
+  __syncthreads();
+  k1s_increments(L, a, S, tid, nthr);
+  __syncthreads();
+  k1s_positions(L, a, S, tid);
+  __syncthreads();
+  k1s_records<true>(L, a, q, S, tid, nthr);
+  if (tid == 0) k1s_base_cost(L, a, q, S);
+  if (!q.scored) {
+    if (tid == 0 && L.n_points) L.n_points[q.local] = 0;
+    return;
+  }
+  k1s_footprint(L, a, S, tid, nthr);
+  __syncthreads();
+  k1s_quotients(a, S, tid, nthr);
+  __syncthreads();
+  if (tid == 0) k1s_scan(L, a, q, S);
 }
 
 #pragma clang fp contract(fast)
@@ -1370,8 +1424,7 @@ __device__ __forceinline__ int64_t robot_sample_of_item(const sfw_launch &L, int
 // Stage the per-launch constants and the initial dead flags into LDS; returns false when no item of
 // this wave is live (rejected by K1, or by a pedestrian contact inside the shared prefix).
 template <bool GROUPS, bool CONSTS>
-__device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout &s, int lane, int G, int Gn,
-                                           int64_t first_local) {
+__device__ __forceinline__ void stage_consts(const sfw_launch &L, const lds_layout &s, int lane) {
   const int A = L.A;
   // lds_at() takes offsets into the wave's allocation for LDS addresses: true only while the K2 kernels have no
   // static __shared__ data in front of the dynamic allocation (s.px is the allocation's first byte)
@@ -1388,6 +1441,11 @@ __device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout
     for (int q = lane; q <= L.NG; q += WAVE) s.goff[q] = L.grp_off[q];
     for (int m = lane; m < L.n_grp_mem; m += WAVE) s.gmem[m] = L.grp_mem[m];
   }
+}
+template <bool GROUPS, bool CONSTS>
+__device__ __forceinline__ bool stage_wave(const sfw_launch &L, const lds_layout &s, int lane, int G, int Gn,
+                                           int64_t first_local) {
+  stage_consts<GROUPS, CONSTS>(L, s, lane);
   if (lane < G) {
     int dead = 1;
     if (lane < Gn) {
@@ -1915,11 +1973,29 @@ __device__ __forceinline__ void wait_pair_entries(uint32_t &io, uint32_t &jo) {
 #ifndef SFW_FLAT_WAVES_NOOBS
 #define SFW_FLAT_WAVES_NOOBS 6  // ... the kernel without the laser-point pass (77 VGPRs: six waves per SIMD)
 #endif
-template <typename R, bool GROUPS, int CAP, bool OBS>
-__global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLAT_WAVES : SFW_FLAT_WAVES_NOOBS) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
-  sfwm::fp_mode_for_omod();
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  (void)G_unused;
+// Synchronisation of ONE wave with itself: the LDS executes a wave's operations in issue order, so all that is needed is
+// that the compiler keeps the order.  (What __syncthreads() is for a block of one wave — the flat kernel's — after the
+// backend has dropped its s_barrier; the cycle kernel runs the same body as one wave of a larger block, where a block
+// barrier would wait for waves that are doing something else.)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// What the flat form's wave does with its sample, as the body of two kernels:
+//   CYCLE = false  sfw_social_kernel_flat: one wave per block, robot records from the K1->K2 table, results by finish_wave;
+//   CYCLE = true   sfw_cycle_kernel (small grids: a control cycle in ONE launch): wave 0 of a block whose other waves roll the
+//                  robot out and check its footprint meanwhile.  The robot's records come from that rollout's LDS arrays
+//                  (`k1`), the block meets once — behind this wave's prologue, when the records are there — and the wave
+//                  hands back its social-work sum and contact verdict instead of writing the cost.
+// Same statements either way: costs are bit-identical.
+struct cycle_result {
+  double social_work;  // lane 0
+  int dead;            // 0, or 2 + the step of a pedestrian contact
+};
+#define K2_SYNC() do { if constexpr (CYCLE) wave_sync(); else __syncthreads(); } while (0)
+template <typename R, bool GROUPS, int CAP, bool OBS, bool CYCLE>
+__device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *const smem, const k1s_lds *const k1, cycle_result *const res) {
   const int lane = threadIdx.x;
   const int A = L.A, O = L.O;
   const int NG = GROUPS ? L.NG : 0;
@@ -1929,7 +2005,8 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
   (void)FCX;
   (void)FCY;
   const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, GROUPS, true, L.k.obs_lds != 0);
-  const int64_t first_local = L.item_base + xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd));
+  const int64_t first_local = CYCLE ? static_cast<int64_t>(blockIdx.x)
+                                    : L.item_base + xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd));
   const sfm_consts<R> k0 = make_consts<R, true>(L);  // the prologue's; every step builds its own (below)
   // the five force constants stay in scalar registers for the rollout (a step's copy into VGPRs is five v_mov; read from the
   // kernel arguments every step, a lone wave waited for the scalar loads at the top of each)
@@ -1938,20 +2015,26 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
           s_cvel = sfwm::sgpr_const(fk.c_vel), s_cang = sfwm::sgpr_const(fk.c_ang);
   constexpr bool F32 = sizeof(R) == 4;
   const int step_begin = L.step_begin, step_end = L.step_end;
-  if (!stage_wave<GROUPS, GROUPS>(L, s, lane, 1, 1, first_local)) {
-    if (L.phase == SFW_PHASE_SUFFIX) finish_wave(s, lane, 1, 1, first_local, 0.0);  // inherited contact
-    if (L.phase == SFW_PHASE_PREFIX && lane == 0) L.out_dead[first_local] = s.dead[0];
-    return;
+  if constexpr (CYCLE) {  // (the block runs this wave for a scored sample only; the costmap's verdict is formed beside it)
+    stage_consts<GROUPS, GROUPS>(L, s, lane);
+    if (lane == 0) s.dead[0] = 0;
+    wave_sync();
+  } else {
+    if (!stage_wave<GROUPS, GROUPS>(L, s, lane, 1, 1, first_local)) {
+      if (L.phase == SFW_PHASE_SUFFIX) finish_wave(s, lane, 1, 1, first_local, 0.0);  // inherited contact
+      if (L.phase == SFW_PHASE_PREFIX && lane == 0) L.out_dead[first_local] = s.dead[0];
+      return;
+    }
   }
   clock_probe(0);
   // wave-uniform, but formed from table loads: made scalar explicitly (as a VGPR pair it is held — in scratch, once the
   // laser-point pass needs the registers — across the whole rollout for the two lanes that fetch the robot records)
-  const int64_t rsample_v = robot_sample_of_item(L, first_local);
+  const int64_t rsample_v = CYCLE ? 0 : robot_sample_of_item(L, first_local);
   const int64_t rsample = static_cast<int64_t>(
       (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rsample_v >> 32)))) << 32) |
       static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rsample_v))));
 
-  if (L.resume) {  // resume from the record of the item's (parent) class
+  if (!CYCLE && L.resume) {  // resume from the record of the item's (parent) class
     const sfw_cls_agent *rec = L.in_state + source_class_of_item(L, first_local) * A;
     for (int sl = lane; sl < A; sl += WAVE) {
       const sfw_cls_agent c = rec[sl];
@@ -2004,23 +2087,23 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
     s.px[sl] = s.py[sl] = s.vx[sl] = s.vy[sl] = 0.0;
     s.fcx[sl] = s.fcy[sl] = s.fjx[sl] = s.fjy[sl] = 0.0;
   }
-  __syncthreads();
+  K2_SYNC();
   auto add_group_forces = [&](const sfm_consts<R> &k, const agent_consts &c) {
     for (int q = lane; q < NG; q += WAVE) s.gcen[q] = double2{0.0, 0.0};
-    __syncthreads();
+    K2_SYNC();
     for (int sl = lane; sl < A; sl += WAVE)
       if (s.grp[sl] >= 0) {
         atomicAdd(&s.gcen[s.grp[sl]].x, s.px[sl]);
         atomicAdd(&s.gcen[s.grp[sl]].y, s.py[sl]);
       }
-    __syncthreads();
+    K2_SYNC();
     for (int sl = lane; sl < A; sl += WAVE)
       if (sl != 0) {
         const double2 gf = group_force<R>(k, c, s, NG, 0, A, sl, sl, s.px[sl], s.py[sl]);
         s.fcx[sl] += gf.x;
         s.fcy[sl] += gf.y;
       }
-    __syncthreads();
+    K2_SYNC();
   };
   if constexpr (GROUPS) {
     if (!L.resume) add_group_forces(k0, load_agent_consts(late_args(), F32));  // a class record's force already has them
@@ -2033,6 +2116,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
 
   // robot record of a step: lanes 0 and 1 bring 16 bytes each from the K1 table straight to LDS
   auto fetch_robot = [&](const sfw_robot_step *rstep, int64_t stride, int st, int buf) {
+    if constexpr (CYCLE) return;  // (the records are in the block's LDS: read where they are used)
 #ifdef SFW_DBG_PLAIN_ROBOT
     if (lane == 0) s.rsb[buf] = rstep[static_cast<int64_t>(st) * stride + rsample];
     return;
@@ -2166,7 +2250,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     }
-    __syncthreads();
+    K2_SYNC();
 #if defined(SFW_ABL_HALF_LDS)
     if (lane < A) { s.fcx[lane] += abl_fx; s.fcy[lane] += abl_fy; abl_ix = s.px[lane] + 1e-3; abl_iy = s.py[lane]; abl_fx = abl_fy = 0.0; }
 #endif
@@ -2174,7 +2258,12 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
     const late_launch La = late_args();
     const agent_consts c = load_agent_consts(La, F32);
     const sfw_agent_const *const agent_c = La->agent_c;
-    const sfw_robot_step rs = s.rsb[step & 1];
+    // the cycle kernel's first block barrier, behind the first pair pass (which needs the handed-over state only): the wave
+    // that rolled the robot out has arrived, its records are in LDS
+    if constexpr (CYCLE) {
+      if (step == step_begin) __syncthreads();
+    }
+    const sfw_robot_step rs = CYCLE ? sfw_robot_step{k1->xs[step + 1], k1->ys[step + 1], k1->vxs[step], k1->vys[step]} : s.rsb[step & 1];
     // (fetched ONE step ahead.  Two steps ahead into a third slot — so that no barrier of a step finds the fetch still in
     // flight — was measured on the control cycle and is slower: +3 % without laser points, +5 % with them, 32 bytes of scratch)
     if (step + 1 < step_end) fetch_robot(La->rstep, La->rstep_stride, step + 1, (step + 1) & 1);
@@ -2224,7 +2313,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
     }
     if (with_obs) {
       // Obstacle term: the robot at its pre-step position (Wr's obstacle part), a person at its new position.
-      __syncthreads();
+      K2_SYNC();
       if (c.obs_tasks) {
         // Every (agent, segment) pair is a task; the wave walks them 256 at a time, 16 agents x 16 segments per round (same
         // sums in the same order as obstacle_sums).  Lane l: segment l / 4 of the agents a0 + l % 4 + {0, 4, 8, 12} — four
@@ -2289,6 +2378,8 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
           // j0 + (l >> 1) % SL of lane group l / (2 SL).
           auto reduce = [&](auto sl_tag) {
             constexpr int SL = decltype(sl_tag)::value;
+            // (the slots of a round go through LDS SL at a time: axj / opart are sized for KA <= 4 and a whole number of phases)
+            static_assert(KA <= 4 && (SL == 2 || KA % SL == 0), "SFW_OBS_KA: at most four agent slots per lane");
 #pragma unroll
             for (int j0 = 0; j0 < KA; j0 += SL) {
 #if defined(SFW_ABL_NOREDUCE)
@@ -2300,7 +2391,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
 #pragma unroll
                 for (int u = 0; u < SL; ++u)
                   s.opart[u * WAVE + lane] = double2{static_cast<double>(axj[j0 + u]), static_cast<double>(ayj[j0 + u])};
-                __syncthreads();
+                K2_SYNC();
                 const int comp = lane & 1, js = (lane >> 1) & (SL - 1), gsub = lane / (2 * SL);  // gsub < 4 for lane < 8 SL
                 const int a = a0 + gsub + OBS_AGENT_LANES * (j0 + js);
                 if (lane < 8 * SL && a < A) {
@@ -2322,7 +2413,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
                   if (a != 0) *acc = fma(static_cast<double>(t), sc, acc0);
                   else if (comp == 0) s.swp[0] += wr0 + fast_norm(f, f_other);
                 }
-                __syncthreads();
+                K2_SYNC();
               }
             }
           };
@@ -2343,7 +2434,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
             s.fcy[a] = fma(ty, sc, s.fcy[a]);
           }
         }
-        __syncthreads();
+        K2_SYNC();
       }
       if (lane == 0) {
         s.px[0] = rs.x;
@@ -2363,7 +2454,7 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
           }
         }
     }
-    __syncthreads();
+    K2_SYNC();
     if (s.dead[0] != 0) break;
     if constexpr (GROUPS) add_group_forces(k, c);
   }
@@ -2385,8 +2476,25 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
   }
   double sw_acc = 0.0;
   for (int sl = lane; sl < A; sl += WAVE) sw_acc += s.swp[sl];
-  finish_wave(s, lane, 1, 1, first_local, sw_acc);
+  if constexpr (CYCLE) {
+    // finish_wave's reduction (the same 64-lane shuffle tree); the cost is formed by the wave that holds the costmap's verdict
+    for (int off = WAVE / 2; off > 0; off >>= 1) sw_acc += __shfl_down(sw_acc, off, WAVE);
+    if (lane == 0) {
+      res->social_work = sw_acc;
+      res->dead = s.dead[0];
+    }
+  } else {
+    finish_wave(s, lane, 1, 1, first_local, sw_acc);
+  }
   clock_probe(1);
+}
+#undef K2_SYNC
+template <typename R, bool GROUPS, int CAP, bool OBS>
+__global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLAT_WAVES : SFW_FLAT_WAVES_NOOBS) sfw_social_kernel_flat(const sfw_launch L, const int G_unused) {
+  sfwm::fp_mode_for_omod();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  (void)G_unused;
+  social_flat_wave<R, GROUPS, CAP, OBS, false>(L, smem, nullptr, nullptr);
 }
 
 // ===========================================================================
@@ -2425,6 +2533,24 @@ __device__ __forceinline__ sfw_sel sel_shfl_down(const sfw_sel &a, int off) {
   r.n_valid = __shfl_down(a.n_valid, off, WAVE);
   return r;
 }
+// one sample's cost against the running best of a thread (ref :394-404; see sel_less)
+__device__ __forceinline__ void sel_consider(sfw_sel &best, double c, const double *linvels, const double *angvels, int nw,
+                                             int64_t t, int64_t index_base) {
+  if (!(c >= 0.0)) return;
+  best.n_valid += 1;
+  const double lin = linvels[t / nw], ang = angvels[t % nw];
+  const bool selectable = c < 10000.0 || (c == 10000.0 && (lin > 0.0 || (lin == 0.0 && ang == 0.0)));
+  if (!selectable) return;
+  sfw_sel cand;
+  cand.cost = c;
+  cand.neg_linvel = -lin;
+  cand.abs_angvel = fabs(ang);
+  cand.neg_index = -(index_base + t);
+  cand.n_valid = 0;
+  const long long nv = best.n_valid;
+  if (sel_less(cand, best)) best = cand;
+  best.n_valid = nv;
+}
 constexpr int ARGMIN_BLOCK = 256;
 __device__ __forceinline__ sfw_sel block_reduce(sfw_sel v) {
   __shared__ sfw_sel wave_best[ARGMIN_BLOCK / WAVE];
@@ -2450,20 +2576,7 @@ sfw_argmin_stage1(const double *costs, const double *linvels, const double *angv
        t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     const double c = costs[t];
     if (costs_host) costs_host[t] = c;
-    if (!(c >= 0.0)) continue;
-    best.n_valid += 1;
-    const double lin = linvels[t / nw], ang = angvels[t % nw];
-    const bool selectable = c < 10000.0 || (c == 10000.0 && (lin > 0.0 || (lin == 0.0 && ang == 0.0)));
-    if (!selectable) continue;
-    sfw_sel cand;
-    cand.cost = c;
-    cand.neg_linvel = -lin;
-    cand.abs_angvel = fabs(ang);
-    cand.neg_index = -(index_base + t);
-    cand.n_valid = 0;
-    const long long nv = best.n_valid;
-    if (sel_less(cand, best)) best = cand;
-    best.n_valid = nv;
+    sel_consider(best, c, linvels, angvels, nw, t, index_base);
   }
   best = block_reduce(best);
   if (threadIdx.x == 0) {
@@ -2495,6 +2608,103 @@ __global__ void __launch_bounds__(64) sfw_key_table_kernel(const sfw_sel *sel, d
       else if (isfinite(s.cost)) v = c == 0 ? s.cost : c == 1 ? s.neg_linvel : c == 2 ? s.abs_angvel : static_cast<double>(s.neg_index);
     }
     table[e] = v;
+  }
+}
+
+// ===========================================================================
+// One launch per control cycle (grids of up to CYCLE_MAX_SAMPLES samples: the reference's own 5 x 9, :64-85)
+// ===========================================================================
+// K1 + K2 + K3 of such a grid were three launches back to back (14 + 56 + 5 us at 5 people and 40 steps,
+// profiles/r05_cycle_timeline.txt), each a lone wave per sample waiting for the one before.  Here a sample is one block of
+// four waves, each with a job of its own, and the block meets twice:
+//   wave 0   the pedestrians (social_flat_wave<.., CYCLE>): stages the agents, runs the first pair pass — none of it needs the
+//            robot's trajectory — | barrier 1 | then the rollout, the robot's post-step records read from the LDS arrays
+//            wave 1 has filled (no K1->K2 table, no load in flight across a step);
+//   wave 1   the robot's recurrences (k1s_velocities / _increments / _positions, a wave's worth of lanes) | barrier 1 |
+//   1, 2, 3  Trajectory points, the pedestrian-free cost terms, the footprint tasks (k1s_footprint) — beside the rollout;
+//            | barrier 2 |
+//   wave 1   (default FP mode) the in-order costmap scan, the cost = base + w_s x social work, and the selection: the last
+//            block to finish — one atomic counter — reduces the cost vector under the reference's order (sel_consider) and
+//            leaves vector and record in the host's pinned mirror too.
+// A sample the costmap rejects is integrated all the same (its verdict comes from the waves beside it) and discarded.  The
+// three-kernel path remains for everything else and as this kernel's checker (tests/test_cycle_kernel_gpu.py: bit-identical).
+constexpr int CYCLE_BLOCK = 4 * WAVE;
+constexpr int CYCLE_MAX_SAMPLES = 1024;
+template <typename R, bool GROUPS, bool OBS>
+__global__ void __launch_bounds__(CYCLE_BLOCK) sfw_cycle_kernel(const sfw_launch L, const int k2_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // K2 wave's area (from LDS address 0) | k1s_lds | cycle_result
+  const int tid = threadIdx.x, wave = tid / WAVE, lane = tid % WAVE;
+  const int S = L.S;
+  size_t k1_bytes;
+  const k1s_lds a(smem + k2_bytes, S, &k1_bytes);
+  cycle_result *const res = reinterpret_cast<cycle_result *>(smem + k2_bytes + k1_bytes);
+  const k1s_sample q = k1s_sample_of(L, blockIdx.x);
+  // pedestrians to integrate?  (no agents at all, or a robot alone without a laser point: social work identically 0)
+  const bool social = q.scored && L.A > 0 && !(L.A == 1 && L.O == 0 && L.NG == 0);
+  if (wave == 0 && social) {
+    sfwm::fp_mode_for_omod();
+    social_flat_wave<R, GROUPS, 64, OBS, true>(L, smem, &a, res);  // (holds barrier 1)
+  } else {
+    if (wave == 1) {
+      if (lane == 0) k1s_head(L, q);
+      k1s_velocities(L, a, q, S, lane);
+      wave_sync();
+      k1s_increments(L, a, S, lane, WAVE);
+      wave_sync();
+      k1s_positions(L, a, S, lane);
+    }
+    __syncthreads();  // barrier 1
+    const int ftid = social ? tid - WAVE : tid, fn = social ? CYCLE_BLOCK - WAVE : CYCLE_BLOCK;
+    k1s_records<false>(L, a, q, S, ftid, fn);
+    if (ftid == fn - 1) k1s_base_cost(L, a, q, S);
+    if (q.scored) k1s_footprint(L, a, S, ftid, fn);
+  }
+  __syncthreads();  // barrier 2
+  if (wave != 1) return;
+  const int64_t t = q.t;
+  if (q.scored) {
+    k1s_quotients(a, S, lane, WAVE);
+    wave_sync();
+  }
+  if (lane == 0) {
+    if (!q.scored) {
+      if (L.n_points) L.n_points[q.local] = 0;
+    } else {
+      double base = 0.0;
+      const bool legal = k1s_scan(L, a, q, S, &base);
+      const int d = social ? res->dead : 0;
+      if (legal && L.A > 0) {  // (no agent vector at all: scan_finish has written the cost)
+        if (d == 0) {
+          L.costs[t] = base + L.p.social_weight * (social ? res->social_work : 0.0);  // finish_wave / sfw_no_social_kernel
+        } else {
+          L.costs[t] = SFW_COST_INVALID;
+          L.status[t] = SFW_ST_INVALID;
+          if (L.coll_step) L.coll_step[t] = d - 2;
+        }
+      } else if (!legal && L.force_alive && d >= 2 && L.coll_step) {
+        L.coll_step[t] = d - 2;  // point dumps: the contact in front of the illegal pose (finish_wave, force_alive)
+      }
+    }
+  }
+  // ---- selection by the last block to get here
+  __threadfence();
+  unsigned prev = 0;
+  if (lane == 0) prev = atomicAdd(L.cycle_counter, 1u);
+  prev = __shfl(prev, 0, WAVE);
+  if (prev != gridDim.x - 1) return;
+  __threadfence();
+  sfw_sel best = sel_empty();
+  for (int64_t i = lane; i < L.chunk_count; i += WAVE) {
+    const int64_t ti = L.chunk_begin + i;
+    const double c = __builtin_nontemporal_load(L.costs + ti);
+    if (L.costs_host) L.costs_host[ti] = c;
+    sel_consider(best, c, L.linvels, L.angvels, L.nw, ti, L.index_base);
+  }
+  for (int off = WAVE / 2; off > 0; off >>= 1) best = sel_merge(best, sel_shfl_down(best, off));
+  if (lane == 0) {
+    *L.sel_out = best;
+    if (L.sel_host) *L.sel_host = best;
+    *L.cycle_counter = 0u;  // for the next launch (stream order)
   }
 }
 
@@ -2876,4 +3086,52 @@ hipError_t sfw_launch_argmin(const double *costs, const double *linvels, const d
                      angvels, nw, T, index_base, partials, costs_host, static_cast<sfw_sel *>(nullptr));
   hipLaunchKernelGGL(sfw_argmin_stage2, dim3(1), dim3(ARGMIN_BLOCK), 0, stream, partials, blocks, out, sel_host);
   return hipGetLastError();
+}
+
+// ---- one launch per control cycle ------------------------------------------------------------------------------------
+static size_t cycle_k2_bytes(const sfw_launch &L, bool obs_lds) {
+  const wave_plan fl{1, 0, true};
+  const bool social = L.A > 0 && !(L.A == 1 && L.O == 0 && L.NG == 0);
+  return social ? ((lds_bytes_for(fl, L.A, L.O, L.NG, L.n_grp_mem, obs_lds) + 15) & ~size_t(15)) : 0;
+}
+// Does sfw_launch_cycle take this launch?  A whole (unshared, single-chunk) rollout of a small grid whose K2 would run the
+// flat form on 64-double planes, or has no pedestrians to integrate.  SFW_CYCLE_FUSED=0 in the environment (read at every
+// launch: tests flip it): never.
+bool sfw_cycle_applies(const sfw_launch &L) {
+  if (const char *e = std::getenv("SFW_CYCLE_FUSED"))
+    if (e[0] == '0') return false;
+  if (L.phase != SFW_PHASE_WHOLE || L.resume || L.chunk_begin != 0 || L.chunk_count <= 0 || L.chunk_count > CYCLE_MAX_SAMPLES) return false;
+  if (L.S > K1_SMALL_MAX_STEPS || !L.cycle_counter || !L.sel_out) return false;
+  const bool social = L.A > 0 && !(L.A == 1 && L.O == 0 && L.NG == 0);
+  if (social) {
+    const int cus = L.n_cu > 0 ? L.n_cu : SFW_DEFAULT_CUS;
+    if (flat_cap(L.A) != 64 || !L.pair_tab || !plan_for(L.A, L.chunk_count, L.O, L.k2_form, cus).flat) return false;
+  }
+  const wave_plan fl{1, 0, true};
+  const bool obs_lds = social && obs_in_lds(fl, L.A, L.O, L.NG, L.n_grp_mem, L.chunk_count, L.n_cu > 0 ? L.n_cu : SFW_DEFAULT_CUS);
+  size_t k1_bytes = 0;
+  (void)k1s_lds(nullptr, L.S, &k1_bytes);
+  return cycle_k2_bytes(L, obs_lds) + k1_bytes + 16 <= 64 * 1024;
+}
+template <typename R> static hipError_t launch_cycle_typed(const sfw_launch &L_in, hipStream_t stream) {
+  sfw_launch L = L_in;
+  const bool social = L.A > 0 && !(L.A == 1 && L.O == 0 && L.NG == 0);
+  const wave_plan fl{1, 0, true};
+  L.k.obs_lds = (social && obs_in_lds(fl, L.A, L.O, L.NG, L.n_grp_mem, L.chunk_count, L.n_cu > 0 ? L.n_cu : SFW_DEFAULT_CUS)) ? 1 : 0;
+  const size_t k2 = cycle_k2_bytes(L, L.k.obs_lds != 0);
+  size_t k1_bytes = 0;
+  (void)k1s_lds(nullptr, L.S, &k1_bytes);
+  const size_t lds = k2 + k1_bytes + 16;
+  const dim3 grid(static_cast<unsigned>(L.chunk_count)), block(CYCLE_BLOCK);
+  const int k2i = static_cast<int>(k2);
+  if (L.NG > 0) hipLaunchKernelGGL((sfw_cycle_kernel<R, true, true>), grid, block, lds, stream, L, k2i);
+  else if (L.O > 0) hipLaunchKernelGGL((sfw_cycle_kernel<R, false, true>), grid, block, lds, stream, L, k2i);
+  else hipLaunchKernelGGL((sfw_cycle_kernel<R, false, false>), grid, block, lds, stream, L, k2i);
+  return hipGetLastError();
+}
+hipError_t sfw_launch_cycle(const sfw_launch &L, hipStream_t stream) {
+#ifndef SFW_STRICT_BUILD
+  if (L.p.precision == SFW_PRECISION_F32) return launch_cycle_typed<float>(L, stream);
+#endif
+  return launch_cycle_typed<double>(L, stream);
 }

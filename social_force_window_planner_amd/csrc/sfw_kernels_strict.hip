@@ -3,12 +3,14 @@
 // this build differs by one degree of the angle's polynomial only.  Same source, compiled a second time: the degrees are
 // compile-time constants of the Horner chains (an issue slot each), so the choice between the two is a choice between two
 // sets of kernels, made per launch by sfw_capi.hip.  Every external symbol of sfw_kernels.hip is renamed for this
-// translation unit; only sfw_launch_social_strict is used (the pose rollout, the footprint check and the selection do not
+// translation unit; only sfw_launch_social_strict and sfw_launch_cycle_strict are used (the pose rollout, the footprint check and the selection do not
 // evaluate a polynomial and exist once).
 #define SFW_STRICT_BUILD 1
 #define SFW_ASIN_DEG 8
 #define SFW_EXP_DEG 9
 #define sfw_launch_social sfw_launch_social_strict
+#define sfw_launch_cycle sfw_launch_cycle_strict
+#define sfw_cycle_applies sfw_strict_unused_cycle_applies
 #define sfw_samples_per_wave sfw_strict_unused_samples_per_wave
 #define sfw_social_organisation sfw_strict_unused_social_organisation
 #define sfw_derive sfw_strict_unused_derive

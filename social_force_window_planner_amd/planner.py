@@ -214,6 +214,12 @@ class HipScorer:
                                          len(ang), C.byref(ga), index_base), "sfw_grid_stage")
         self._grid = (len(lin), len(ang))
 
+    def prepared(self, robot_state, linvels, angvels, goal_args, index_base=0):
+        """The blocking call with its arguments marshalled ONCE (a C caller builds its structs once too): step() is
+        sfw_grid_stage + sfw_grid_launch + sfw_grid_fetch into the same cost buffer every cycle, three foreign calls and
+        nothing else — no numpy array, no ctypes struct is created per call."""
+        return PreparedGrid(self, robot_state, linvels, angvels, goal_args, index_base)
+
     def launch(self):
         self._check(lib().sfw_grid_launch(self._h), "sfw_grid_launch")
 
@@ -322,6 +328,45 @@ def plan_info_of_rank(multi, r):
     return info.as_dict()
 
 
+class PreparedGrid:
+    """See HipScorer.prepared."""
+
+    def __init__(self, scorer, robot_state, linvels, angvels, goal_args, index_base):
+        self.scorer = scorer
+        self.lin, self.ang = _f64(linvels).copy(), _f64(angvels).copy()
+        self.rs, self.ga = SfwRobotState(*robot_state), SfwGoalArgs(*goal_args)
+        self.costs = np.empty(len(self.lin) * len(self.ang), dtype=np.float64)
+        self.best, self.key = SfwBest(), SfwBestKey()
+        L = lib()
+        self._stage, self._launch, self._fetch = L.sfw_grid_stage, L.sfw_grid_launch, L.sfw_grid_fetch
+        self._stage_args = (scorer._h, C.byref(self.rs), self.lin.ctypes.data, len(self.lin), self.ang.ctypes.data, len(self.ang),
+                            C.byref(self.ga), index_base)
+        self._fetch_args = (scorer._h, self.costs.ctypes.data, C.byref(self.best), C.byref(self.key))
+        self._fetch_args_nocost = (scorer._h, None, C.byref(self.best), C.byref(self.key))
+        scorer._grid = (len(self.lin), len(self.ang))
+
+    def step(self, want_costs=True):
+        """Returns (costs — the SAME array every call —, best, key)."""
+        s = self.scorer
+        rc = self._stage(*self._stage_args)
+        if rc != SFW_OK:
+            s._check(rc, "sfw_grid_stage")
+        rc = self._launch(s._h)
+        if rc != SFW_OK:
+            s._check(rc, "sfw_grid_launch")
+        rc = self._fetch(*(self._fetch_args if want_costs else self._fetch_args_nocost))
+        if rc != SFW_OK:
+            s._check(rc, "sfw_grid_fetch")
+        return (self.costs if want_costs else None), self.best.as_dict(), self.key.as_tuple()
+
+    def relaunch(self):
+        """launch + selection fetch of the grid staged last (no stage, no cost vector)."""
+        s = self.scorer
+        s._check(self._launch(s._h), "sfw_grid_launch")
+        s._check(self._fetch(*self._fetch_args_nocost), "sfw_grid_fetch")
+        return None, self.best.as_dict(), self.key.as_tuple()
+
+
 class MultiScorer:
     """sfw_multi_*: one process driving one handle per listed device (rows of the grid split over them, one
     RCCL all-reduce(min) of the [R,5] key table).  exchange = SFW_MULTI_HOST_REDUCE lets a device be listed
@@ -333,7 +378,7 @@ class MultiScorer:
         devs = (C.c_int * len(devices))(*devices)
         rc = lib().sfw_multi_create(C.byref(self.params), devs, len(devices), exchange, C.byref(self._m))
         if rc != SFW_OK:
-            raise SfwError(rc, "sfw_multi_create")
+            raise SfwError(rc, "sfw_multi_create", (lib().sfw_multi_last_error(None) or b"").decode())
         self.n_ranks = lib().sfw_multi_ranks(self._m)
 
     def close(self):
@@ -382,7 +427,8 @@ class MultiScorer:
         """sfw_multi_describe: devices, exchange and what the RCCL communicators report about themselves."""
         class Desc(C.Structure):
             _fields_ = [("ranks", C.c_int32), ("exchange", C.c_int32), ("communicators", C.c_int32), ("comm_size", C.c_int32),
-                        ("rccl_version", C.c_int32), ("devices", C.c_int32 * 64), ("comm_devices", C.c_int32 * 64)]
+                        ("rccl_version", C.c_int32), ("devices", C.c_int32 * 64), ("comm_devices", C.c_int32 * 64),
+                        ("rccl_path", C.c_char * 512), ("rccl_found", C.c_char * 64)]
 
         d = Desc()
         lib().sfw_multi_describe.argtypes = [C.c_void_p, C.c_void_p]
@@ -390,7 +436,7 @@ class MultiScorer:
         n = min(d.ranks, 64)
         return {"ranks": d.ranks, "exchange": "rccl" if d.exchange == 0 else "host_reduce", "communicators": d.communicators,
                 "comm_size": d.comm_size, "rccl_version": d.rccl_version, "devices": list(d.devices[:n]),
-                "comm_devices": list(d.comm_devices[:n])}
+                "comm_devices": list(d.comm_devices[:n]), "rccl_path": d.rccl_path.decode(), "rccl_found": d.rccl_found.decode()}
 
     def rank_rows(self, r):
         """(first row, rows) of rank r in the last score_grid."""

@@ -26,7 +26,7 @@ def test_header_symbols_all_exported():
     assert declared == set(EXPORTED_SYMBOLS), declared ^ set(EXPORTED_SYMBOLS)
     exported = planner.exported_symbols()
     assert all(exported.values()), [n for n, ok in exported.items() if not ok]
-    assert planner.lib().sfw_abi_version() == 1
+    assert planner.lib().sfw_abi_version() == 2
 
 
 def test_params_default_matches_python_mirror():

@@ -216,3 +216,51 @@ def test_cpp_multi_device_example():
     r = subprocess.run([os.path.join(ROOT, "build", "multi_device")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rccl R=1: identical" in r.stdout and "host-reduce R=2: identical" in r.stdout
+
+
+def test_the_rccl_that_was_resolved_is_reported():
+    """which librccl the one-process path binds is stated, not guessed.  Three fresh processes:
+    (a) plain: the loader's search, the path ncclAllReduce came from is reported;
+    (b) a process that has torch (and with it torch's bundled RCCL) mapped reuses THAT copy — no second RCCL beside it;
+    (c) SFW_RCCL_LIB names a file: honoured first; a file that cannot be loaded is an error, not a silent fall-through."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, os, sys
+sys.path.insert(0, os.getcwd())
+if os.environ.get("WITH_TORCH") == "1":
+    import torch
+    torch.cuda.init()
+from social_force_window_planner_amd import planner
+from social_force_window_planner_amd._abi import SFW_MULTI_RCCL, default_params
+try:
+    m = planner.MultiScorer(default_params(), devices=(0,), exchange=SFW_MULTI_RCCL)
+    d = m.describe()
+    m.close()
+    maps = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l]
+    print(json.dumps({"path": d["rccl_path"], "found": d["rccl_found"], "version": d["rccl_version"], "mapped": sorted(set(maps))}))
+except Exception as e:
+    print(json.dumps({"error": str(e)}))
+'''
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("SFW_RCCL_LIB", "WITH_TORCH")}
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=e, capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert lines, r.stderr[-2000:]
+        return json.loads(lines[-1])
+
+    a = run()
+    assert "error" not in a and os.path.isfile(a["path"]) and "librccl" in a["path"] and a["version"] > 0, a
+    assert a["found"] in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"), a
+    b = run(WITH_TORCH="1")
+    assert "error" not in b and b["found"] == "already mapped", b
+    assert "torch" in b["path"] and len(b["mapped"]) == 1 and os.path.samefile(b["mapped"][0], b["path"]), b
+    c = run(SFW_RCCL_LIB=a["path"])
+    assert c["found"] == "SFW_RCCL_LIB" and os.path.samefile(c["path"], a["path"]), c
+    d = run(SFW_RCCL_LIB="/nonexistent/librccl.so")
+    assert "error" in d and "SFW_RCCL_LIB" in d["error"], d

@@ -685,3 +685,37 @@ def test_people_that_can_never_move(oracle_mod, hip_mod):
     o.load_scene(scene)
     oc2, _ = o.score_grid(scene.robot_state, lin, scene.angvels, scene.goal_args, n_threads=8)
     assert not np.allclose(oc, oc2, rtol=1e-6)
+
+
+def test_the_braking_robot_hole_is_flagged(oracle_mod, hip_mod):
+    """the one configuration whose reference result is not reproduced — a person that can never move next
+    to a robot that moves now and BRAKES TO A STOP inside the rollout of a linvel = 0 sample — is visible:
+    sfw_grid_plan_info().rest_noise_unreproduced is 1 for exactly those stages.  Every row the robot keeps moving in still
+    meets the oracle, and so does the whole grid when the flag is 0."""
+    w = dataclasses.replace(syn.WORKLOADS["cfg2"], nv=9, nw=9, n_people=10, seed=741)
+    scene = syn.make_scene(w)
+    ag = scene.agents
+    lin, ang = scene.linvels, scene.angvels
+    assert lin[0] == 0.0 and scene.robot_state[3] > 0
+
+    def flag(robot_state=None, linvels=None, goal_args=None, sim_time=1.0):
+        g = hip_mod.HipScorer(default_params(sim_time=sim_time))
+        g.load_scene(scene)
+        g.stage(robot_state or scene.robot_state, lin if linvels is None else linvels, ang, goal_args or scene.goal_args)
+        return g.plan_info()["rest_noise_unreproduced"]
+
+    assert flag() == 0                                   # nobody is pinned
+    _stand(ag[4])
+    ag[4].desired_velocity = 0.0
+    assert flag() == 1                                   # 0.3 m/s at 1 m/s^2: at rest after 0.3 s of the 1 s horizon
+    assert flag(linvels=lin[1:]) == 0                    # no sample stops the robot
+    rs0 = (scene.robot_state[0], scene.robot_state[1], scene.robot_state[2], 0.0, 0.0, 0.0)
+    ag[0].vx = ag[0].vy = 0.0
+    assert flag(robot_state=rs0) == 0                    # standing from the start: reproduced (pinned_rest_table)
+    ag[0].vx = scene.robot_state[3]
+    slow = (0.2, scene.goal_args[1], scene.goal_args[2], scene.goal_args[3], scene.goal_args[4])
+    assert flag(goal_args=slow) == 0                     # 0.3 m/s at 0.2 m/s^2: still moving at the horizon
+    assert flag(goal_args=slow, sim_time=2.0) == 1       # ... but not at a 2 s horizon
+    # the rows in which the robot keeps moving meet the oracle as ever
+    oc, ob, gc, gb = _both(oracle_mod, hip_mod, scene, default_params(), lin=lin[1:])
+    _assert_parity(oc, ob, gc, gb, RTOL_F64)
