@@ -242,9 +242,17 @@ int sfw_grid_stage(sfw_handle h, const sfw_robot_state *rs,
  * Everything stays in HBM; no host sync. */
 int sfw_grid_launch(sfw_handle h);
 int sfw_grid_sync(sfw_handle h);
-/* D2H of the cost vector (nullable) and the local selection (nullable). */
+/* Wait for the launch; the cost vector (nullable) and the local selection (nullable).  Since round 6 the selection kernels
+ * themselves leave vector and record in a pinned host buffer of the handle (grids of up to SFW_MIRROR_MAX_MB, default
+ * 64 MB, of costs): the call is a wait on the stream — polling it for up to SFW_SPIN_US microseconds, default 20000,
+ * before it blocks — plus one memcpy into costs_out; larger grids are copied device-to-host here. */
 int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out,
                    sfw_best_key *key_out);
+/* The cost vector of the last fetched launch where the handle holds it on the host (nv * nw doubles, sample order;
+ * valid until the next sfw_grid_launch / sfw_score_* on this handle), or NULL when this launch was not mirrored (then
+ * pass costs_out).  A caller that only reads the vector — a marker publisher, the tests — saves the memcpy:
+ * sfw_grid_fetch(h, NULL, &best, NULL) and this. */
+const double *sfw_grid_costs_view(sfw_handle h);
 /* How the staged grid will be launched.  levels > 0: the shared-prefix
  * rollout is in use — under the acceleration limits (sfw_planner.hpp:457-463)
  * the robot's first steps are bit-identical for all samples of a class (same

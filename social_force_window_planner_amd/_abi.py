@@ -163,6 +163,7 @@ EXPORTED_SYMBOLS = (
     "sfw_grid_launch",
     "sfw_grid_sync",
     "sfw_grid_fetch",
+    "sfw_grid_costs_view",
     "sfw_grid_plan_info",
     "sfw_plan_shared_prefix",
     "sfw_plan_row_blocks",

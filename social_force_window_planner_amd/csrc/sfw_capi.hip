@@ -106,9 +106,17 @@ struct sfw_planner_s {
   // and every stage packs them into ONE pinned arena and issues ONE H2D copy into `world`
   // (device pointers below are offsets into it) — a control cycle is latency-bound and each
   // separate copy costs as much as a kernel launch.
-  dev_buf<uint8_t> cells;
-  uint32_t size_x = 0, size_y = 0;
+  dev_buf<uint8_t> cells;               // the snapshot on the device when it is too large to ride in `world`
+  uint32_t size_x = 0, size_y = 0;      // ... as the last stage uploaded it
   double origin_x = 0, origin_y = 0, resolution = 0;
+  struct map_geometry {
+    uint32_t size_x, size_y;
+    double origin_x, origin_y, resolution;
+  } map_new{0, 0, 0, 0, 0};             // what sfw_set_costmap handed over last (pin_map holds its cells)
+  bool cells_dirty = false;             // ... and the device has not seen yet
+  bool cells_in_world = false;          // the device copy is the head of `world` (small maps), else `cells`
+  size_t world_cells_bytes = 0;         // bytes of that head
+  const uint8_t *d_cells = nullptr;
   bool have_costmap = false;
   std::vector<double> h_footprint;  // 2K
   int K = 0;
@@ -150,6 +158,7 @@ struct sfw_planner_s {
   bool staged = false, launched = false, launched_timed = false;
   bool launched_cycle = false;        // the last launch was the one-kernel control cycle (sfw_grid_plan_info)
   dev_buf<unsigned> cycle_counter;    // its "blocks done" word (zero between launches)
+  bool fetched = false;               // ... and a fetch has waited for it (sfw_grid_costs_view)
   bool mirrored = false;              // the last launch's selection kernels left costs + record in pin_mirror (sfw_launch_argmin)
   size_t mirror_max_bytes = size_t(64) << 20;  // SFW_MIRROR_MAX_MB in the environment of sfw_create; 0: always copy
   long spin_us = 20000;               // SFW_SPIN_US in the environment of sfw_create: how long a fetch polls the stream before
@@ -275,6 +284,8 @@ hipError_t wait_stream(sfw_handle h) {
   }
   return hipStreamSynchronize(h->stream);
 }
+// ... after which no upload enqueued on it is still reading its pinned staging area
+void stream_is_idle(sfw_handle h) { h->pin_map.pending = h->pin_world.pending = h->pin_cls.pending = false; }
 
 // the register-form K2 addresses a sample's record inside a row of the K1->K2 table by a 32-bit byte offset
 constexpr int64_t kRowLimit = static_cast<int64_t>((uint64_t(1) << 32) / sizeof(sfw_robot_step)) - 1;
@@ -313,7 +324,7 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.nw = h->nw;
   L.chunk_begin = begin;
   L.chunk_count = count;
-  L.cells = h->cells.p;
+  L.cells = h->d_cells;
   L.size_x = h->size_x;
   L.size_y = h->size_y;
   L.origin_x = h->origin_x;
@@ -960,9 +971,9 @@ int plan_tables_device(sfw_handle h, int64_t chunk, bool may_start_poses) {
     fill_launch(h, L, 0, T, T);
     if (!sfw_rollout_is_fused(L)) {  // (the fused small-grid K1 is one launch with the costmap part, and may capture points)
       h->clock_cleared = false;
-      if (h->timing) {  // the clock probe of a timed launch is cleared here, in front of the rollout (launch_common)
+      if (h->timing) {  // the clock probe of a timed launch is cleared by the pose rollout itself (clear_clock_probe)
         SFW_HIP(h, h->clock.reserve(4));
-        SFW_HIP(h, hipMemsetAsync(h->clock.p, 0, 4 * sizeof(unsigned long long), h->stream));
+        L.clock_probe = h->clock.p;
         h->clock_cleared = true;
       }
       if (h->timing) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
@@ -1070,7 +1081,11 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   {  // one arena, one copy: footprint | agents blob | linvels | angvels | relative-rest terms | pinned-rest table | class tables
     auto up16 = [](size_t b) { return (b + 15) & ~size_t(15); };
     const bool rest = !h->rest_pairs.empty();
-    const size_t o_fp = 0, o_ag = o_fp + up16(sizeof(double) * (h->h_footprint.empty() ? 2 : h->h_footprint.size())),
+    // a small costmap (<= 256 KB: a local costmap of 500 x 500 cells) is the head of the arena; it is sent when it has changed
+    const size_t n_cells = static_cast<size_t>(h->map_new.size_x) * h->map_new.size_y;
+    const bool merge = n_cells <= (size_t(256) << 10);
+    const size_t cells_head = merge ? up16(n_cells) : 0;
+    const size_t o_fp = cells_head, o_ag = o_fp + up16(sizeof(double) * (h->h_footprint.empty() ? 2 : h->h_footprint.size())),
                  o_lin = o_ag + up16(h->h_agents.size()), o_ang = o_lin + up16(sizeof(double) * nv),
                  o_rest = o_ang + up16(sizeof(double) * nw),
                  o_pin = o_rest + (rest ? up16(sizeof(double) * 2 * static_cast<size_t>(h->A)) : 0),
@@ -1080,8 +1095,25 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
                  o_cls = o_pin + ((h->pin_rest_on && rs->vx == 0.0 && rs->vy == 0.0 && h->A > 1) ? up16(sizeof(double) * pin_doubles) : 0),
                  total = o_cls + up16(sizeof(int32_t) * h->cls_ints.size());
     SFW_HIP(h, h->pin_world.reserve(total));
+    // (a `world` that moves, or whose head changes size, has lost its copy of the cells)
+    bool send_cells = h->cells_dirty || (merge && (!h->cells_in_world || h->world_cells_bytes != cells_head || total > h->world.cap));
     SFW_HIP(h, h->world.reserve(total));
     char *pb = h->pin_world.p;
+    if (!merge && send_cells) {
+      SFW_HIP(h, h->cells.reserve(n_cells));
+      SFW_HIP(h, hipMemcpyAsync(h->cells.p, h->pin_map.p, n_cells, hipMemcpyHostToDevice, h->stream));
+      SFW_HIP(h, h->pin_map.mark(h->stream));
+      send_cells = false;
+    }
+    if (merge && send_cells) std::memcpy(pb, h->pin_map.p, n_cells);
+    h->cells_dirty = false;
+    h->cells_in_world = merge;
+    h->world_cells_bytes = cells_head;
+    h->size_x = h->map_new.size_x;
+    h->size_y = h->map_new.size_y;
+    h->origin_x = h->map_new.origin_x;
+    h->origin_y = h->map_new.origin_y;
+    h->resolution = h->map_new.resolution;
     if (!h->h_footprint.empty()) std::memcpy(pb + o_fp, h->h_footprint.data(), sizeof(double) * h->h_footprint.size());
     if (!h->h_agents.empty()) std::memcpy(pb + o_ag, h->h_agents.data(), h->h_agents.size());
     std::memcpy(pb + o_lin, lin, sizeof(double) * nv);
@@ -1102,7 +1134,11 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
                                  reinterpret_cast<const sfw_agent_const *>(h->h_agents.data() + h->ao_cst), h->A,
                                  reinterpret_cast<double *>(pb + o_pin));
     ph.mark("pack");
-    SFW_HIP(h, hipMemcpyAsync(h->world.p, pb, total, hipMemcpyHostToDevice, h->stream));
+    {
+      const size_t from = send_cells ? 0 : cells_head;
+      SFW_HIP(h, hipMemcpyAsync(h->world.p + from, pb + from, total - from, hipMemcpyHostToDevice, h->stream));
+    }
+    h->d_cells = merge ? reinterpret_cast<const uint8_t *>(h->world.p) : h->cells.p;
     ph.mark("h2d");
     SFW_HIP(h, h->pin_world.mark(h->stream));
     ph.mark("evrec");
@@ -1192,7 +1228,12 @@ int launch_common(sfw_handle h) {
     SFW_HIP(h, h->clock.reserve(4));
     // (cleared by the stage already when it started the pose rollout: in front of it, where the GPU waits for the host's
     // planning anyway, instead of between the rollout and the first K2 dispatch)
-    if (!(poses_done && h->clock_cleared)) SFW_HIP(h, hipMemsetAsync(h->clock.p, 0, 4 * sizeof(unsigned long long), h->stream));
+    // ... or will be by the pose rollout this launch enqueues; only the small-grid kernels (a block per sample, no kernel in
+    // front of their K2 part) need the memset
+    sfw_launch probe0;
+    fill_launch(h, probe0, 0, std::min<int64_t>(T, chunk), chunk);
+    if (!(poses_done && h->clock_cleared) && sfw_rollout_is_fused(probe0))
+      SFW_HIP(h, hipMemsetAsync(h->clock.p, 0, 4 * sizeof(unsigned long long), h->stream));
     if (!poses_done) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
   }
   h->clock_cleared = false;
@@ -1224,6 +1265,7 @@ int launch_common(sfw_handle h) {
   // the cost vector and the selection record reach the host through the selection kernels themselves (pinned mirror): the
   // fetch then only waits for the stream.  Grids whose vector is larger than SFW_MIRROR_MAX_MB (default 64) keep the copy.
   h->mirrored = false;
+  h->fetched = false;
   double *costs_host = nullptr;
   sfw_sel *sel_host = nullptr;
   if (h->mirror_max_bytes > 0 && sizeof(double) * static_cast<size_t>(T) <= h->mirror_max_bytes) {
@@ -1553,17 +1595,13 @@ int sfw_set_costmap(sfw_handle h, const uint8_t *cells, uint32_t size_x, uint32_
     return fail(h, SFW_ERR_INVALID_ARG, "set_costmap: null cells, zero size or non-positive resolution");
   SFW_HIP(h, hipSetDevice(h->device));
   const size_t n = static_cast<size_t>(size_x) * size_y;
-  // stream order keeps a launch already in flight on the old snapshot; no synchronisation
-  SFW_HIP(h, h->cells.reserve(n));
-  SFW_HIP(h, h->pin_map.reserve(n));
+  // The snapshot is taken here (the caller's buffer may change on return) and reaches the device with the NEXT stage — like
+  // footprint and agents — as part of that stage's one arena copy when it is small (a control cycle's local costmap: one
+  // copy per cycle instead of two with the host's call-to-call latency between them), by a copy of its own otherwise.
+  SFW_HIP(h, h->pin_map.reserve(n));  // (waits for a copy out of it that is still pending)
   std::memcpy(h->pin_map.p, cells, n);
-  SFW_HIP(h, hipMemcpyAsync(h->cells.p, h->pin_map.p, n, hipMemcpyHostToDevice, h->stream));
-  SFW_HIP(h, h->pin_map.mark(h->stream));
-  h->size_x = size_x;
-  h->size_y = size_y;
-  h->origin_x = origin_x;
-  h->origin_y = origin_y;
-  h->resolution = resolution;
+  h->map_new = {size_x, size_y, origin_x, origin_y, resolution};
+  h->cells_dirty = true;
   h->have_costmap = true;
   return SFW_OK;
 }
@@ -1697,6 +1735,8 @@ int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out, sfw_best
   if (h->mirrored) {  // the launch's selection kernels wrote both to pin_mirror: nothing to copy, only to wait for
     const size_t all_bytes = sizeof(double) * static_cast<size_t>(T);
     SFW_HIP(h, wait_stream(h));
+    stream_is_idle(h);
+    h->fetched = true;
     if (costs_out) std::memcpy(costs_out, h->pin_mirror.p, all_bytes);
     std::memcpy(&s, h->pin_mirror.p + all_bytes, sizeof(s));
   } else {
@@ -1705,11 +1745,17 @@ int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out, sfw_best
     const char *src = reinterpret_cast<const char *>(h->d_sel) - cost_bytes;
     SFW_HIP(h, hipMemcpyAsync(h->pin_out.p, src, cost_bytes + sizeof(sfw_sel), hipMemcpyDeviceToHost, h->stream));
     SFW_HIP(h, wait_stream(h));
+    stream_is_idle(h);
     if (costs_out) std::memcpy(costs_out, h->pin_out.p, cost_bytes);
     std::memcpy(&s, h->pin_out.p + cost_bytes, sizeof(s));
   }
   sel_to_best(h, s, best_out, key_out);
   return SFW_OK;
+}
+
+const double *sfw_grid_costs_view(sfw_handle h) {
+  if (!h || !h->launched || !h->mirrored || !h->fetched) return nullptr;
+  return reinterpret_cast<const double *>(h->pin_mirror.p);
 }
 
 int sfw_score_grid(sfw_handle h, const sfw_robot_state *rs, const double *linvels, int32_t nv,

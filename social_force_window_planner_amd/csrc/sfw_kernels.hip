@@ -246,7 +246,13 @@ __device__ __forceinline__ bool scan_finish(const sfw_launch &L, int64_t t, int6
 }
 
 // K1a: one thread per sample.
+// (a timed launch's clock probe is cleared here, by the kernel every K2 dispatch of the launch is ordered behind: a memset of
+// its own in front of the rollout was a 4 us operation with its 6 us gap at the head of every timed step)
+__device__ __forceinline__ void clear_clock_probe(const sfw_launch &L) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && L.clock_probe) L.clock_probe[0] = L.clock_probe[1] = L.clock_probe[2] = L.clock_probe[3] = 0ull;
+}
 __global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
+  clear_clock_probe(L);
   const int64_t local = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (local >= L.chunk_count) return;
   rollout_sample(L, local, [&](int i, const sfw_pose_frame &f) {
@@ -269,6 +275,7 @@ __global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
 constexpr int K1A_TEAM = 8;
 __global__ void __launch_bounds__(64) sfw_rollout_team_kernel(const sfw_launch L) {
   constexpr int TEAMS = WAVE / K1A_TEAM;
+  clear_clock_probe(L);
   __shared__ double r_th[TEAMS][K1A_TEAM], r_vx[TEAMS][K1A_TEAM], r_vy[TEAMS][K1A_TEAM];  // [team][step of the round]
   __shared__ double2 r_inc[TEAMS][K1A_TEAM];
   __shared__ double r_px[TEAMS][K1A_TEAM + 1], r_py[TEAMS][K1A_TEAM + 1];                  // pose before step q; [nst]: after the round

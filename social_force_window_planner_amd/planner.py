@@ -111,6 +111,8 @@ def lib():
         L.sfw_multi_rank_rows.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.sfw_plan_row_blocks.argtypes = [vp, C.c_int32, vp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                                           C.c_double, C.c_int32, C.c_int32, C.c_int32, vp]
+        L.sfw_grid_costs_view.argtypes = [vp]
+        L.sfw_grid_costs_view.restype = C.c_void_p
         L.sfw_plan_shared_prefix.argtypes = [vp, C.c_int32, vp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                                              C.c_double, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.POINTER(C.c_int32)]
         L.sfw_multi_grid_points.argtypes = [vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32)]
@@ -214,11 +216,11 @@ class HipScorer:
                                          len(ang), C.byref(ga), index_base), "sfw_grid_stage")
         self._grid = (len(lin), len(ang))
 
-    def prepared(self, robot_state, linvels, angvels, goal_args, index_base=0):
+    def prepared(self, robot_state, linvels, angvels, goal_args, index_base=0, zero_copy=False):
         """The blocking call with its arguments marshalled ONCE (a C caller builds its structs once too): step() is
         sfw_grid_stage + sfw_grid_launch + sfw_grid_fetch into the same cost buffer every cycle, three foreign calls and
         nothing else — no numpy array, no ctypes struct is created per call."""
-        return PreparedGrid(self, robot_state, linvels, angvels, goal_args, index_base)
+        return PreparedGrid(self, robot_state, linvels, angvels, goal_args, index_base, zero_copy)
 
     def launch(self):
         self._check(lib().sfw_grid_launch(self._h), "sfw_grid_launch")
@@ -240,6 +242,17 @@ class HipScorer:
         self._check(lib().sfw_grid_fetch(self._h, costs.ctypes.data if want_costs else None, C.byref(best),
                                          C.byref(key)), "sfw_grid_fetch")
         return costs, best.as_dict(), key.as_tuple()
+
+    def costs_view(self):
+        """sfw_grid_costs_view as a read-only numpy array over the handle's pinned cost vector (valid until the next launch),
+        or None when the last launch was not mirrored."""
+        p = lib().sfw_grid_costs_view(self._h)
+        if not p:
+            return None
+        nv, nw = self._grid
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(nv * nw,))
+        a.flags.writeable = False
+        return a
 
     def plan_info(self):
         """How the staged grid will be launched (shared-prefix split step, classes, chunks)."""
@@ -331,7 +344,7 @@ def plan_info_of_rank(multi, r):
 class PreparedGrid:
     """See HipScorer.prepared."""
 
-    def __init__(self, scorer, robot_state, linvels, angvels, goal_args, index_base):
+    def __init__(self, scorer, robot_state, linvels, angvels, goal_args, index_base, zero_copy=False):
         self.scorer = scorer
         self.lin, self.ang = _f64(linvels).copy(), _f64(angvels).copy()
         self.rs, self.ga = SfwRobotState(*robot_state), SfwGoalArgs(*goal_args)
@@ -344,9 +357,11 @@ class PreparedGrid:
         self._fetch_args = (scorer._h, self.costs.ctypes.data, C.byref(self.best), C.byref(self.key))
         self._fetch_args_nocost = (scorer._h, None, C.byref(self.best), C.byref(self.key))
         scorer._grid = (len(self.lin), len(self.ang))
+        self.zero_copy = zero_copy
+        self._view, self._view_ptr, self._view_arr = L.sfw_grid_costs_view, None, None
 
     def step(self, want_costs=True):
-        """Returns (costs — the SAME array every call —, best, key)."""
+        """Returns (costs — the SAME array every call, or with zero_copy a read-only view of the handle's own —, best, key)."""
         s = self.scorer
         rc = self._stage(*self._stage_args)
         if rc != SFW_OK:
@@ -354,6 +369,19 @@ class PreparedGrid:
         rc = self._launch(s._h)
         if rc != SFW_OK:
             s._check(rc, "sfw_grid_launch")
+        if want_costs and self.zero_copy:
+            # the vector where the launch's selection kernels left it on the host (sfw_grid_costs_view): no memcpy of it
+            rc = self._fetch(*self._fetch_args_nocost)
+            if rc != SFW_OK:
+                s._check(rc, "sfw_grid_fetch")
+            p = self._view(s._h)
+            if p:
+                if p != self._view_ptr:
+                    a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(self.costs.size,))
+                    a.flags.writeable = False
+                    self._view_ptr, self._view_arr = p, a
+                return self._view_arr, self.best.as_dict(), self.key.as_tuple()
+            self.zero_copy = False  # (a grid too large for the mirror: copy from here on)
         rc = self._fetch(*(self._fetch_args if want_costs else self._fetch_args_nocost))
         if rc != SFW_OK:
             s._check(rc, "sfw_grid_fetch")
