@@ -209,8 +209,8 @@ struct sfw_planner_s {
   // per-sample outputs + per-chunk table
   dev_buf<int32_t> status, coll_step;
   dev_buf<double> base_cost, costs;  // costs: T doubles followed by the sfw_sel record (one D2H fetches both)
-  dev_buf<sfw_robot_step> rstep;
-  dev_buf<sfw_pose_frame> frame;
+  dev_buf<sfw_unit> ptab, cs_tab;   // the K1 tables (sfw_device.h sfw_unit), sized for table_chunk samples per step row
+  int64_t table_chunk = 0;          // samples per chunk the tables of the staged grid hold
   dev_buf<int16_t> fcode;
   dev_buf<sfw_sel> partials;
   sfw_sel *d_sel = nullptr;
@@ -221,8 +221,7 @@ struct sfw_planner_s {
   // scratch outputs of sfw_grid_points_batch's K1 re-run (kept across calls: hipMalloc/hipFree synchronise the device)
   dev_buf<int32_t> pts_status, pts_coll;
   dev_buf<double> pts_base, pts_costs;
-  dev_buf<sfw_robot_step> pts_rstep;
-  dev_buf<sfw_pose_frame> pts_frame;
+  dev_buf<sfw_unit> pts_ptab, pts_cs;
   dev_buf<int16_t> pts_fcode;
   // sfw_set_params bumps params_epoch; the table sizes and the shared-prefix plan carry the epoch they were made for
   uint64_t params_epoch = 1, plan_epoch = 0;
@@ -287,8 +286,9 @@ hipError_t wait_stream(sfw_handle h) {
 // ... after which no upload enqueued on it is still reading its pinned staging area
 void stream_is_idle(sfw_handle h) { h->pin_map.pending = h->pin_world.pending = h->pin_cls.pending = false; }
 
-// the register-form K2 addresses a sample's record inside a row of the K1->K2 table by a 32-bit byte offset
-constexpr int64_t kRowLimit = static_cast<int64_t>((uint64_t(1) << 32) / sizeof(sfw_robot_step)) - 1;
+// the register-form K2 addresses a unit inside a step row of the position / velocity table by a 32-bit byte offset: a row of
+// `chunk` positions and at most chunk + 2 velocities (a one-column grid) must stay below 4 GB
+constexpr int64_t kRowLimit = static_cast<int64_t>((uint64_t(1) << 32) / (2 * sizeof(sfw_unit))) - 2;
 
 int num_steps_of(const sfw_params &p) {
   int n = static_cast<int>(p.sim_time / p.sim_granularity + 0.5);  // ref :519
@@ -307,6 +307,12 @@ int check_params(sfw_handle h, const sfw_params *p) {
     return fail(h, SFW_ERR_INVALID_ARG, "sfm_force_factor_social / _obstacle must be >= 0");
   return SFW_OK;
 }
+
+// Units per step row of the position / velocity table for chunks of `stride` samples of an nw-column grid: the positions,
+// then one velocity unit per grid row a chunk can touch (it may begin and end inside a row)
+int64_t table_row_units(int64_t stride, int nw) { return stride + stride / (nw > 0 ? nw : 1) + 2; }
+// bytes of the K1 tables per sample and step (position unit + footprint code; the per-row / per-column units are noise)
+constexpr size_t kTableBytesPerSampleStep = sizeof(sfw_unit) + sizeof(int16_t);
 
 // Fill the launch descriptor for samples [begin, begin+count).
 void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int64_t stride) {
@@ -354,8 +360,9 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.base_cost = h->base_cost.p;
   L.costs = h->costs.p;
   L.coll_step = h->coll_step.p;
-  L.rstep = h->rstep.p;
-  L.frame = h->frame.p;
+  L.ptab = h->ptab.p;
+  L.cs_tab = h->cs_tab.p;
+  L.row_units = table_row_units(stride, h->nw);
   L.fcode = h->fcode.p;
   L.rstep_stride = stride;
   L.points = nullptr;
@@ -945,7 +952,7 @@ int64_t plan_tables_host(sfw_handle h, int *err) {
   const int S = num_steps_of(h->params);
   h->early_poses = false;
   int64_t chunk = static_cast<int64_t>(
-      h->table_budget_bytes / ((sizeof(sfw_robot_step) + sizeof(sfw_pose_frame) + sizeof(int16_t)) * S));
+      h->table_budget_bytes / (kTableBytesPerSampleStep * S));
   if (chunk < 1024) chunk = 1024;
   if (chunk > kRowLimit) chunk = kRowLimit;
   if (chunk > T) chunk = T;
@@ -958,9 +965,10 @@ int64_t plan_tables_host(sfw_handle h, int *err) {
 int plan_tables_device(sfw_handle h, int64_t chunk, bool may_start_poses) {
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
   const int S = num_steps_of(h->params);
-  SFW_HIP(h, h->rstep.reserve(static_cast<size_t>(chunk) * S));
-  SFW_HIP(h, h->frame.reserve(static_cast<size_t>(chunk) * S));
+  SFW_HIP(h, h->ptab.reserve(static_cast<size_t>(table_row_units(chunk, h->nw)) * S));
+  SFW_HIP(h, h->cs_tab.reserve(static_cast<size_t>(h->nw) * S));
   SFW_HIP(h, h->fcode.reserve(static_cast<size_t>(chunk) * S));
+  h->table_chunk = chunk;
   if (!h->prefix_steps.empty())
     for (size_t b = 0; b < (h->cls_two ? 2u : 1u); ++b) {
       SFW_HIP(h, h->cls_dead[b].reserve(static_cast<size_t>(h->cls_max)));
@@ -1211,7 +1219,7 @@ int launch_common(sfw_handle h) {
     }
   }
   const int S = num_steps_of(h->params);
-  int64_t chunk = static_cast<int64_t>(std::min(h->rstep.cap, std::min(h->frame.cap, h->fcode.cap)) / S);
+  int64_t chunk = h->table_chunk;  // (plan_tables_device: what the tables were sized for, under the live step count)
   if (chunk > kRowLimit) chunk = kRowLimit;
   if (chunk > T) chunk = T;
   if (chunk < 1) return fail(h, SFW_ERR_STATE, "robot-step table too small");
@@ -1538,8 +1546,8 @@ int sfw_destroy(sfw_handle h) {
   h->coll_step.release();
   h->base_cost.release();
   h->costs.release();
-  h->rstep.release();
-  h->frame.release();
+  h->ptab.release();
+  h->cs_tab.release();
   h->fcode.release();
   h->partials.release();
   h->clock.release();
@@ -1553,8 +1561,8 @@ int sfw_destroy(sfw_handle h) {
   h->pts_coll.release();
   h->pts_base.release();
   h->pts_costs.release();
-  h->pts_rstep.release();
-  h->pts_frame.release();
+  h->pts_ptab.release();
+  h->pts_cs.release();
   h->pts_fcode.release();
   h->pin_map.release();
   h->pin_world.release();
@@ -1871,8 +1879,7 @@ int sfw_grid_plan_info(sfw_handle h, sfw_plan_info *out) {
   if (!h->prefix_steps.empty()) {
     out->chunks = static_cast<int32_t>(h->prefix_chunks.size());
   } else {
-    const int S = num_steps_of(h->params);
-    int64_t chunk = static_cast<int64_t>(std::min(h->rstep.cap, std::min(h->frame.cap, h->fcode.cap)) / S);
+    int64_t chunk = h->table_chunk;
     if (chunk > T) chunk = T;
     out->chunks = chunk > 0 ? static_cast<int32_t>((T + chunk - 1) / chunk) : 0;
   }
@@ -1986,8 +1993,8 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
   hipError_t e = h->pts_status.reserve(n);
   if (e == hipSuccess) e = h->pts_base.reserve(n);
   if (e == hipSuccess) e = h->pts_costs.reserve(n);
-  if (e == hipSuccess) e = h->pts_rstep.reserve(static_cast<size_t>(S) * n);
-  if (e == hipSuccess) e = h->pts_frame.reserve(static_cast<size_t>(S) * n);
+  if (e == hipSuccess) e = h->pts_ptab.reserve(static_cast<size_t>(S) * static_cast<size_t>(table_row_units(count, h->nw)));
+  if (e == hipSuccess) e = h->pts_cs.reserve(static_cast<size_t>(S) * h->nw);
   if (e == hipSuccess) e = h->pts_fcode.reserve(static_cast<size_t>(S) * n);
   if (e == hipSuccess) {
     sfw_launch L;
@@ -1996,8 +2003,8 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
     L.base_cost = h->pts_base.p - first;
     L.costs = h->pts_costs.p - first;
     L.coll_step = nullptr;  // keep the launch's contact steps
-    L.rstep = h->pts_rstep.p;
-    L.frame = h->pts_frame.p;
+    L.ptab = h->pts_ptab.p;
+    L.cs_tab = h->pts_cs.p;
     L.fcode = h->pts_fcode.p;
     L.points = h->points.p;
     L.n_points = h->n_points.p;
@@ -2030,7 +2037,8 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
     L.base_cost = h->pts_base.p - first;
     L.costs = h->pts_costs.p - first;
     L.coll_step = h->pts_coll.p - first;
-    L.rstep = h->pts_rstep.p;
+    L.ptab = h->pts_ptab.p;
+    L.cs_tab = h->pts_cs.p;
     L.force_alive = 1;
     SFW_HIP(h, hipMemsetAsync(h->pts_coll.p, 0xff, sizeof(int32_t) * n, h->stream));  // -1: no contact
     SFW_HIP(h, launch_social_of(L, h->stream));

@@ -37,7 +37,7 @@ enum : int32_t { SFW_ST_VALID = 0, SFW_ST_INVALID = 1, SFW_ST_SKIPPED = 2 };
 
 // Post-step robot agent state for one (step, sample): what the reference
 // writes into myagents[0] at src/sfw_planner.cpp:600-604 (position and the
-// robot-LOCAL velocity).  32 bytes, one coalesced line per 4 samples.
+// robot-LOCAL velocity).  32 bytes: the form a K2 wave holds it in (LDS).
 struct __attribute__((aligned(32))) sfw_robot_step {
   double x, y, vx, vy;
 };
@@ -45,6 +45,19 @@ struct __attribute__((aligned(32))) sfw_robot_step {
 // Pre-step footprint frame of one (step, sample): position and cos/sin(theta).
 struct __attribute__((aligned(32))) sfw_pose_frame {
   double x, y, c, s;
+};
+
+// The K1 -> K2 / K1b tables in memory (round 6; rounds 1-5 stored the two 32-byte records above per (step, sample): 64 B).
+// Of a robot step only the POSITION depends on both sample axes: the velocity sequence is the linear sample's alone
+// (computeNewVelocity, ref :581-583), the heading — hence cos / sin — the angular sample's (ref :588), and the pose BEFORE
+// step i is the position AFTER step i - 1.  So per step one row of 16-byte units
+//     [ position after the step, one unit (x, y) per sample of the chunk | velocity (vx, vy) of the step, one unit per grid row ]
+// (sfw_launch.ptab, row_units units per step) and one row (cos, sin) per grid column (sfw_launch.cs_tab): 16 B per (step,
+// sample) written by the pose rollout and read back by K1b and K2 — a quarter of the traffic that bounded the rollout
+// (cfg2: 42 MB in 16 us) — and a K2 lane still fetches its half of a record by ONE 16-byte load from a row base plus an
+// offset that is fixed for the rollout.
+struct __attribute__((aligned(16))) sfw_unit {
+  double a, b;
 };
 
 // Person constants shared by every sample (device copy, SoA-friendly AoS).
@@ -173,11 +186,12 @@ struct sfw_launch {
   double *base_cost;     // T : vel + distance + angle + costmap terms (ref :663-666)
   double *costs;         // T : final cost or sentinel
   int32_t *coll_step;    // T : step at which a pedestrian touched the robot (ref :613-627), -1 if none; nullable
-  // per-chunk table, indexed [step][local sample]
-  sfw_robot_step *rstep;
-  sfw_pose_frame *frame;
-  int16_t *fcode;        // footprint cost per (step, sample): -3,-2,-1 or 0..253
-  int64_t rstep_stride;  // samples per step row
+  // per-chunk tables (see sfw_unit)
+  sfw_unit *ptab;        // [step][row_units]: positions of the chunk's samples, then velocities of its grid rows
+  sfw_unit *cs_tab;      // [step][nw]: cos / sin of the heading before the step, per grid column
+  int64_t row_units;     // units per step row of ptab (>= rstep_stride + grid rows the chunk touches)
+  int16_t *fcode;        // footprint cost per (step, sample): -3,-2,-1 or 0..253, [step][rstep_stride]
+  int64_t rstep_stride;  // samples per step row (position units in a ptab row, codes in an fcode row)
   // optional Trajectory-points dump (x,y,theta per pre-step pose) of the chunk's samples
   double *points;        // nullable, chunk_count x S x 3 doubles
   int32_t *n_points;     // nullable, chunk_count ints

@@ -157,12 +157,27 @@ __device__ __forceinline__ float normalize_angle_f(float val, float mn, float mx
   return mx - fmodf(mn - val, mx - mn);
 }
 
+// ---- the K1 tables (sfw_device.h sfw_unit) ---------------------------------------------------------------------------
+// grid row of a chunk-local sample, counted from the chunk's first row (the velocity unit of its ptab row)
+__device__ __forceinline__ int64_t vel_row_of(const sfw_launch &L, int64_t local) {
+  return (L.chunk_begin + local) / L.nw - L.chunk_begin / L.nw;
+}
+// One step of one sample as the pose rollout leaves it: the post-step position always; the step's velocity by the first
+// sample of every grid row inside the chunk, cos / sin of the pre-step heading by the chunk's first nw samples (one per
+// column) — the same values whoever writes them.
+__device__ __forceinline__ void put_robot_step(const sfw_launch &L, int64_t local, int i, double xn, double yn, double vx,
+                                               double vy, double c, double s) {
+  sfw_unit *const row = L.ptab + static_cast<int64_t>(i) * L.row_units;
+  row[local] = sfw_unit{xn, yn};
+  const int64_t t = L.chunk_begin + local;
+  if (local == 0 || t % L.nw == 0) row[L.rstep_stride + vel_row_of(L, local)] = sfw_unit{vx, vy};
+  if (local < L.nw) L.cs_tab[static_cast<int64_t>(i) * L.nw + t % L.nw] = sfw_unit{c, s};
+}
+
 // Sequential pose integration of one sample (reference :527-:611 without the costmap and the
-// pedestrians): hands the pre-step footprint frame (x_i, y_i, cos th_i, sin th_i) of every step to
-// `put_frame`, writes the post-step robot agent state per step and the pedestrian-independent cost
+// pedestrians): writes the K1 tables (put_robot_step) and the pedestrian-independent cost
 // terms.  Returns false for the never-scored (0,0) sample (whose records are written all the same).
-template <typename FrameSink>
-__device__ __forceinline__ bool rollout_sample(const sfw_launch &L, int64_t local, FrameSink &&put_frame) {
+__device__ __forceinline__ bool rollout_sample(const sfw_launch &L, int64_t local) {
   const int64_t t = L.chunk_begin + local;
   const int iv = static_cast<int>(t / L.nw), iw = static_cast<int>(t % L.nw);
   const double vx_samp = L.linvels[iv], vth_samp = L.angvels[iw], vy_samp = L.vy_samp;
@@ -183,9 +198,6 @@ __device__ __forceinline__ bool rollout_sample(const sfw_launch &L, int64_t loca
   for (int i = 0; i < S; ++i) {
     double s, c;
     sincos(th_i, &s, &c);
-    sfw_pose_frame f;
-    f.x = x_i; f.y = y_i; f.c = c; f.s = s;
-    put_frame(i, f);
     if (L.points) {                                       // ref :578
       double *pt = L.points + (local * S + i) * 3;
       pt[0] = x_i;
@@ -202,9 +214,7 @@ __device__ __forceinline__ bool rollout_sample(const sfw_launch &L, int64_t loca
     x_i = xn;
     y_i = yn;
     th_i = th_i + vth_i * dt;
-    sfw_robot_step r;
-    r.x = x_i; r.y = y_i; r.vx = vx_i; r.vy = vy_i;
-    L.rstep[static_cast<int64_t>(i) * L.rstep_stride + local] = r;
+    put_robot_step(L, local, i, x_i, y_i, vx_i, vy_i, c, s);
   }
   // ref :643-666 without the costmap and social terms (left-to-right sum order kept)
   const double dx = L.ga.wpx - x_i, dy = L.ga.wpy - y_i;
@@ -255,9 +265,7 @@ __global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
   clear_clock_probe(L);
   const int64_t local = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (local >= L.chunk_count) return;
-  rollout_sample(L, local, [&](int i, const sfw_pose_frame &f) {
-    L.frame[static_cast<int64_t>(i) * L.rstep_stride + local] = f;
-  });
+  rollout_sample(L, local);
 }
 
 // K1a again, for GPU-filling grids: TEAMS of eight lanes per sample, eight samples per wave.  One thread per sample leaves a
@@ -268,7 +276,7 @@ __global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
 //       lane 2 also the heading sum (ref :588) — ONE loop for the three lanes;
 //   (2) lane q: sincos of step q's heading and the position increments (vx cos + vy cos(pi/2 + th)) dt (ref :586-587);
 //   (3) lanes 0, 1: the two position sums x += dx_q, y += dy_q over the round;
-//   (4) lane q: the pre-step footprint frame and the post-step robot record of step q, the Trajectory point.
+//   (4) lane q: step q's units of the K1 tables (put_robot_step), the Trajectory point.
 // Eight times the waves (two to eight per SIMD), the sincos of eight steps side by side.  The same operations on the same
 // values in the same order as rollout_sample (no contraction here either): bit-identical tables and cost terms
 // (tests/test_prefix_sharing_gpu.py::test_team_rollout_equals_the_thread_rollout).
@@ -331,23 +339,23 @@ __global__ void __launch_bounds__(64) sfw_rollout_team_kernel(const sfw_launch L
     if (j < 2) {
       const double *const inc = reinterpret_cast<const double *>(r_inc[g]) + j;  // .x or .y of every increment
       pos_out[0] = p;
-      for (int q = 0; q < nst; ++q) pos_out[q + 1] = p = p + inc[2 * q];
+      double d[K1A_TEAM];  // (all the round's increments first, then the dependent additions)
+#pragma unroll
+      for (int q = 0; q < K1A_TEAM; ++q) d[q] = inc[2 * q];
+#pragma unroll
+      for (int q = 0; q < K1A_TEAM; ++q)
+        if (q < nst) pos_out[q + 1] = p = p + d[q];
     }
     __syncthreads();
     if (j < nst && live) {
       const int i = base + j;
-      sfw_pose_frame f;
-      f.x = r_px[g][j]; f.y = r_py[g][j]; f.c = c; f.s = s;
-      L.frame[static_cast<int64_t>(i) * L.rstep_stride + local] = f;
       if (L.points) {                                       // ref :578
         double *pt = L.points + (local * S + i) * 3;
-        pt[0] = f.x;
-        pt[1] = f.y;
+        pt[0] = r_px[g][j];
+        pt[1] = r_py[g][j];
         pt[2] = thq;
       }
-      sfw_robot_step r;
-      r.x = r_px[g][j + 1]; r.y = r_py[g][j + 1]; r.vx = vxq; r.vy = vyq;
-      L.rstep[static_cast<int64_t>(i) * L.rstep_stride + local] = r;
+      put_robot_step(L, local, i, r_px[g][j + 1], r_py[g][j + 1], vxq, vyq, c, s);
     }
     // (no barrier here: the next round's phase (1) writes r_th / r_vx / r_vy, which this round read in front of its second
     // barrier, and r_px / r_py are rewritten behind two more)
@@ -376,8 +384,10 @@ __global__ void __launch_bounds__(256) sfw_footprint_kernel(const sfw_launch L) 
   if (idx >= n * L.S) return;
   const int64_t step = idx / n, local = idx - step * n;
   if (L.status[L.chunk_begin + local] == SFW_ST_SKIPPED) return;
-  const sfw_pose_frame f = L.frame[step * L.rstep_stride + local];
-  const double fc = footprint_cost(L, f.x, f.y, f.c, f.s);  // includes the ref :545 map check
+  // the pose before the step: where the step before it ended (the handed-over pose for step 0), heading by column
+  const sfw_unit pos = step == 0 ? sfw_unit{L.rs.x, L.rs.y} : L.ptab[(step - 1) * L.row_units + local];
+  const sfw_unit cs = L.cs_tab[step * L.nw + (L.chunk_begin + local) % L.nw];
+  const double fc = footprint_cost(L, pos.a, pos.b, cs.a, cs.b);  // includes the ref :545 map check
   L.fcode[step * L.rstep_stride + local] = static_cast<int16_t>(fc);
 }
 
@@ -529,7 +539,16 @@ __device__ __forceinline__ void k1s_positions(const sfw_launch &L, const k1s_lds
   double *const out = tid == 0 ? a.xs : a.ys;
   const double *const inc = reinterpret_cast<const double *>(a.dxy) + tid;  // .x or .y of every increment
   out[0] = p;
-  for (int i = 0; i < S; ++i) out[i + 1] = p = p + inc[2 * i];
+  // eight increments at a time: all eight LDS reads first, then the eight dependent additions (left as one read per addition
+  // the loop was an LDS round trip per step: 40 x ~130 cycles on the path every K2 wave of a control cycle waits for)
+  for (int base = 0; base < S; base += 8) {
+    double d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = inc[2 * min(base + j, S - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (base + j < S) out[base + j + 1] = p = p + d[j];
+  }
 }
 // (4) records, one step per thread: Trajectory points (ref :578) and — for a K2 that reads them from memory — the robot steps
 template <bool TABLE>
@@ -541,11 +560,7 @@ __device__ __forceinline__ void k1s_records(const sfw_launch &L, const k1s_lds &
       pt[1] = a.ys[i];
       pt[2] = a.th[i];
     }
-    if constexpr (TABLE) {
-      sfw_robot_step r;
-      r.x = a.xs[i + 1]; r.y = a.ys[i + 1]; r.vx = a.vxs[i]; r.vy = a.vys[i];
-      L.rstep[static_cast<int64_t>(i) * L.rstep_stride + q.local] = r;
-    }
+    if constexpr (TABLE) put_robot_step(L, q.local, i, a.xs[i + 1], a.ys[i + 1], a.vxs[i], a.vys[i], a.cs[i].x, a.cs[i].y);
   }
 }
 // ... and the pedestrian-free cost terms (one thread): ref :643-666 without the costmap and social terms (left-to-right sum order kept)
@@ -1700,10 +1715,12 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
     hi_[r] = lo_[r] + 8u * static_cast<uint32_t>(A);
   }
   // byte offset of this lane's half record inside a row of the robot-step table (a chunk's row is < 4 GB: one VGPR)
+  // (even lane: the position unit of its sample; odd lane: the velocity unit of the sample's grid row, behind the positions)
   uint32_t rs_off = 0;
-  if (lane < 2 * Gn)
-    rs_off = static_cast<uint32_t>(robot_sample_of_item(L, first_local + (lane >> 1)) * static_cast<int64_t>(sizeof(sfw_robot_step))) +
-             16u * (lane & 1);
+  if (lane < 2 * Gn) {
+    const int64_t rsmp = robot_sample_of_item(L, first_local + (lane >> 1));
+    rs_off = static_cast<uint32_t>(((lane & 1) ? L.rstep_stride + vel_row_of(L, rsmp) : rsmp) * static_cast<int64_t>(sizeof(sfw_unit)));
+  }
 
   // Every load of the prologue has landed before the first step, and every scratch reload of a step before the next (the
   // builtin, unlike an asm string, is seen by the compiler's wait-count pass): otherwise the pass, merging the loop's entry
@@ -1729,7 +1746,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
 #endif
     if (lane < 2 * Gn)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(L.rstep + static_cast<int64_t>(step) * L.rstep_stride) + rs_off),
+          (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(L.ptab + static_cast<int64_t>(step) * L.row_units) + rs_off),
           (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(s.rsb)), 16, 0, 0);
     // ---- pair pass: social forces at the pre-step state -------------------
     // one pair of slot r with the partner at plane offset jo
@@ -2122,22 +2139,25 @@ __device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *cons
   const uint32_t lane_off = 2u * static_cast<uint32_t>(lane);
 
   // robot record of a step: lanes 0 and 1 bring 16 bytes each from the K1 table straight to LDS
-  auto fetch_robot = [&](const sfw_robot_step *rstep, int64_t stride, int st, int buf) {
+  // (lane 0: the position unit of the sample; lane 1: the velocity unit of its grid row, behind the row's positions — two
+  // wave-uniform unit indices, the lane picks one)
+  const int64_t unit_vel_v = CYCLE ? 0 : L.rstep_stride + vel_row_of(L, rsample);  // (an integer division: VALU work, made scalar)
+  const int64_t unit_pos = rsample,
+                unit_vel = static_cast<int64_t>(
+                    (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(unit_vel_v >> 32)))) << 32) |
+                    static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(unit_vel_v))));
+  auto fetch_robot = [&](const sfw_unit *ptab, int64_t row_units, int st, int buf) {
     if constexpr (CYCLE) return;  // (the records are in the block's LDS: read where they are used)
-#ifdef SFW_DBG_PLAIN_ROBOT
-    if (lane == 0) s.rsb[buf] = rstep[static_cast<int64_t>(st) * stride + rsample];
-    return;
-#endif
     int l2 = lane;
-    asm volatile("" : "+v"(l2));  // opaque: 16 * lane is formed here, not held across the rollout
+    asm volatile("" : "+v"(l2));  // opaque: the lane's choice is formed here, not held across the rollout
     if (l2 < 2) {
-      const char *src = reinterpret_cast<const char *>(rstep + static_cast<int64_t>(st) * stride + rsample) + 16 * l2;
+      const char *src = reinterpret_cast<const char *>(ptab + static_cast<int64_t>(st) * row_units + (l2 ? unit_vel : unit_pos));
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                        (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(s.rsb + buf)), 16,
                                        0, 0);
     }
   };
-  if (step_begin < step_end) fetch_robot(L.rstep, L.rstep_stride, step_begin, step_begin & 1);
+  if (step_begin < step_end) fetch_robot(L.ptab, L.row_units, step_begin, step_begin & 1);
   // (the 64-double planes only — crowds of up to 63 agents, every control cycle —: the larger capacities' kernels have no
   // registers to spare, tests/test_kernel_resources.py)
   constexpr bool FIRST_IN_REGS = SFW_FIRST_PAIRS_IN_REGS && CAP == 64;
@@ -2273,7 +2293,7 @@ __device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *cons
     const sfw_robot_step rs = CYCLE ? sfw_robot_step{k1->xs[step + 1], k1->ys[step + 1], k1->vxs[step], k1->vys[step]} : s.rsb[step & 1];
     // (fetched ONE step ahead.  Two steps ahead into a third slot — so that no barrier of a step finds the fetch still in
     // flight — was measured on the control cycle and is slower: +3 % without laser points, +5 % with them, 32 bytes of scratch)
-    if (step + 1 < step_end) fetch_robot(La->rstep, La->rstep_stride, step + 1, (step + 1) & 1);
+    if (step + 1 < step_end) fetch_robot(La->ptab, La->row_units, step + 1, (step + 1) & 1);
     const bool with_obs = OBS && c.O > 0;  // (the GROUPS kernels exist with OBS only and serve both cases)
     // the lane index, opaque once per step: the 64-bit byte offset of the lane's agent constants (48 * lane) is then formed
     // here (two instructions) instead of being held — in scratch, for the 104- and 208-double capacities — across the pair loop

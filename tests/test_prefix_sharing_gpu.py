@@ -134,7 +134,8 @@ def test_plan_info_reports_the_split(hip_mod):
     g.load_scene(small)
     g.stage(small.robot_state, small.linvels, small.angvels, small.goal_args)
     assert g.plan_info() == {"split_step": 0, "levels": 0, "chunks": 1, "classes": 0, "class_steps": 0, "samples": 45,
-                             "organisation": 3, "flat_samples": 0}  # SFW_ORG_FLAT: a control-cycle grid runs one sample per wave
+                             "organisation": 3, "flat_samples": 0,  # SFW_ORG_FLAT: a control-cycle grid runs one sample per wave
+                             "one_launch": 1, "rest_noise_unreproduced": 0}  # ... of ONE kernel (sfw_cycle_kernel)
     # targets far outside the window reachable in the horizon: every sample shares every step but the last
     lin = np.linspace(5.0, 6.0, 64)
     ang = np.linspace(3.0, 4.0, 64)
