@@ -1023,6 +1023,8 @@ int check_lds(sfw_handle h, int64_t items) {
   return SFW_OK;
 }
 
+constexpr size_t kMapMergeMax = size_t(64) << 10;  // costmaps up to this many cells ride in the stage's arena copy
+
 // SFW_DEBUG_STAGE=1 in the environment: every stage / launch prints where its host time went (stderr; tuning aid)
 struct host_phases {
   bool on;
@@ -1064,6 +1066,14 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     return fail(h, SFW_ERR_INVALID_ARG, "grid_stage: non-finite sample velocity");
   host_phases ph("stage:");
   SFW_HIP(h, hipSetDevice(h->device));
+  // a large costmap that has changed goes out first, by a copy of its own that runs while the host plans and packs
+  if (h->cells_dirty && static_cast<size_t>(h->map_new.size_x) * h->map_new.size_y > kMapMergeMax) {
+    const size_t n_cells = static_cast<size_t>(h->map_new.size_x) * h->map_new.size_y;
+    SFW_HIP(h, h->cells.reserve(n_cells));
+    SFW_HIP(h, hipMemcpyAsync(h->cells.p, h->pin_map.p, n_cells, hipMemcpyHostToDevice, h->stream));
+    SFW_HIP(h, h->pin_map.mark(h->stream));
+    h->cells_dirty = false;
+  }
   ph.mark("check+setdev");
   h->h_lin.assign(lin, lin + nv);
   h->h_ang.assign(ang, ang + nw);
@@ -1089,9 +1099,10 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   {  // one arena, one copy: footprint | agents blob | linvels | angvels | relative-rest terms | pinned-rest table | class tables
     auto up16 = [](size_t b) { return (b + 15) & ~size_t(15); };
     const bool rest = !h->rest_pairs.empty();
-    // a small costmap (<= 256 KB: a local costmap of 500 x 500 cells) is the head of the arena; it is sent when it has changed
+    // a small costmap (<= 64 KB: a control cycle's local costmap of 200 x 200 cells) is the head of the arena and sent with
+    // it when it has changed; a larger one has gone out by a copy of its own at the top of this stage (above)
     const size_t n_cells = static_cast<size_t>(h->map_new.size_x) * h->map_new.size_y;
-    const bool merge = n_cells <= (size_t(256) << 10);
+    const bool merge = n_cells <= kMapMergeMax;
     const size_t cells_head = merge ? up16(n_cells) : 0;
     const size_t o_fp = cells_head, o_ag = o_fp + up16(sizeof(double) * (h->h_footprint.empty() ? 2 : h->h_footprint.size())),
                  o_lin = o_ag + up16(h->h_agents.size()), o_ang = o_lin + up16(sizeof(double) * nv),
@@ -1107,12 +1118,7 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     bool send_cells = h->cells_dirty || (merge && (!h->cells_in_world || h->world_cells_bytes != cells_head || total > h->world.cap));
     SFW_HIP(h, h->world.reserve(total));
     char *pb = h->pin_world.p;
-    if (!merge && send_cells) {
-      SFW_HIP(h, h->cells.reserve(n_cells));
-      SFW_HIP(h, hipMemcpyAsync(h->cells.p, h->pin_map.p, n_cells, hipMemcpyHostToDevice, h->stream));
-      SFW_HIP(h, h->pin_map.mark(h->stream));
-      send_cells = false;
-    }
+    if (!merge) send_cells = false;  // (sent above)
     if (merge && send_cells) std::memcpy(pb, h->pin_map.p, n_cells);
     h->cells_dirty = false;
     h->cells_in_world = merge;

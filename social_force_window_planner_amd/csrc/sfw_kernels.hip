@@ -238,7 +238,7 @@ __device__ __forceinline__ bool scan_code(double fc, double &cm, int &n_ok) {
 }
 // Returns whether every pose was legal; *base_out (nullable) receives the pedestrian-free cost of a legal trajectory.
 __device__ __forceinline__ bool scan_finish(const sfw_launch &L, int64_t t, int64_t local, double cm, int n_ok,
-                                            double *base_out = nullptr) {
+                                            double *base_out = nullptr, const double *base_in = nullptr) {
   const int S = L.S;
   if (L.n_points) L.n_points[local] = n_ok;
   if (n_ok < S) {
@@ -247,7 +247,7 @@ __device__ __forceinline__ bool scan_finish(const sfw_launch &L, int64_t t, int6
     return false;
   }
   cm = cm / S;
-  const double base = L.base_cost[t] + L.p.costmap_weight * cm;
+  const double base = (base_in ? *base_in : L.base_cost[t]) + L.p.costmap_weight * cm;
   L.base_cost[t] = base;
   if (base_out) *base_out = base;
   // No agent vector at all: social work is identically 0 and K2 is not launched.
@@ -502,28 +502,42 @@ __device__ __forceinline__ void k1s_head(const sfw_launch &L, const k1s_sample &
   }
   if (L.coll_step) L.coll_step[q.t] = -1;
 }
-// (1) velocities and headings: threads 0, 1, 2 walk ONE loop, each with its own target, velocity and limit (as three
-// branches of an if the wave ran the three recurrences one after the other); thread 2 also sums the heading
-__device__ __forceinline__ void k1s_velocities(const sfw_launch &L, const k1s_lds &a, const k1s_sample &q, int S, int tid) {
+// The three recurrences' running values of one thread (velocity / heading on threads 0-2, position on threads 0-1), so that
+// the phases can be run over a RANGE of steps and resumed (the cycle kernel hands the pedestrians' wave the first steps early)
+struct k1s_state {
+  double v, th, p;
+};
+__device__ __forceinline__ k1s_state k1s_begin(const sfw_launch &L, int tid) {
+  k1s_state st;
+  st.v = tid == 0 ? L.rs.vx : tid == 1 ? L.rs.vy : L.rs.vtheta;
+  st.th = L.rs.theta;
+  st.p = tid == 0 ? L.rs.x : L.rs.y;
+  return st;
+}
+// (1) velocities and headings of steps [i0, i1): threads 0, 1, 2 walk ONE loop, each with its own target, velocity and limit
+// (as three branches of an if the wave ran the three recurrences one after the other); thread 2 also sums the heading
+__device__ __forceinline__ void k1s_velocities(const sfw_launch &L, const k1s_lds &a, const k1s_sample &q, int i0, int i1, int S,
+                                               int tid, k1s_state &st) {
   if (tid >= 3) return;
   const double dt = L.dt;
   const double target = tid == 0 ? q.vx_samp : tid == 1 ? q.vy_samp : q.vth_samp;  // ref :581-583
   const double a_max = tid == 0 ? L.ga.acc_x : tid == 1 ? L.ga.acc_y : L.ga.acc_theta;
-  double v = tid == 0 ? L.rs.vx : tid == 1 ? L.rs.vy : L.rs.vtheta;
-  double th_i = L.rs.theta;
+  double v = st.v, th_i = st.th;
   double *const out = tid == 0 ? a.vxs : tid == 1 ? a.vys : a.th;
-  for (int i = 0; i < S; ++i) {
+  for (int i = i0; i < i1; ++i) {
     v = new_velocity(target, v, a_max, dt);
     // threads 0, 1: the new velocity; thread 2: the heading BEFORE this step's update (ref :586-588 integrate with the old theta)
     out[i] = tid == 2 ? th_i : v;
     th_i = th_i + v * dt;  // (meaningful on thread 2 only)
   }
-  if (tid == 2) *a.th_end = th_i;
+  st.v = v;
+  st.th = th_i;
+  if (tid == 2 && i1 == S) *a.th_end = th_i;
 }
-// (2) sines and position increments, one step per thread
-__device__ __forceinline__ void k1s_increments(const sfw_launch &L, const k1s_lds &a, int S, int tid, int nthr) {
+// (2) sines and position increments of steps [i0, i1), one step per thread
+__device__ __forceinline__ void k1s_increments(const sfw_launch &L, const k1s_lds &a, int i0, int i1, int tid, int nthr) {
   const double dt = L.dt;
-  for (int i = tid; i < S; i += nthr) {
+  for (int i = i0 + tid; i < i1; i += nthr) {
     double s, c, c2 = 0.0, s2 = 0.0;
     sincos(a.th[i], &s, &c);
     if (a.vys[i] != 0.0) sincos(M_PI_2 + a.th[i], &s2, &c2);  // holonomic term, 0 for the grid
@@ -532,23 +546,24 @@ __device__ __forceinline__ void k1s_increments(const sfw_launch &L, const k1s_ld
     a.code[i] = 0;
   }
 }
-// (3) positions: xs[i] = pose before step i, xs[S] = final pose (threads 0 and 1 in ONE loop, as above)
-__device__ __forceinline__ void k1s_positions(const sfw_launch &L, const k1s_lds &a, int S, int tid) {
+// (3) positions: xs[i] = pose before step i, xs[S] = final pose (threads 0 and 1 in ONE loop, as above), steps [i0, i1)
+__device__ __forceinline__ void k1s_positions(const sfw_launch &L, const k1s_lds &a, int i0, int i1, int tid, k1s_state &st) {
   if (tid >= 2) return;
-  double p = tid == 0 ? L.rs.x : L.rs.y;
+  double p = st.p;
   double *const out = tid == 0 ? a.xs : a.ys;
   const double *const inc = reinterpret_cast<const double *>(a.dxy) + tid;  // .x or .y of every increment
-  out[0] = p;
+  if (i0 == 0) out[0] = p;
   // eight increments at a time: all eight LDS reads first, then the eight dependent additions (left as one read per addition
   // the loop was an LDS round trip per step: 40 x ~130 cycles on the path every K2 wave of a control cycle waits for)
-  for (int base = 0; base < S; base += 8) {
+  for (int base = i0; base < i1; base += 8) {
     double d[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) d[j] = inc[2 * min(base + j, S - 1)];
+    for (int j = 0; j < 8; ++j) d[j] = inc[2 * min(base + j, i1 - 1)];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (base + j < S) out[base + j + 1] = p = p + d[j];
+      if (base + j < i1) out[base + j + 1] = p = p + d[j];
   }
+  st.p = p;
 }
 // (4) records, one step per thread: Trajectory points (ref :578) and — for a K2 that reads them from memory — the robot steps
 template <bool TABLE>
@@ -564,14 +579,17 @@ __device__ __forceinline__ void k1s_records(const sfw_launch &L, const k1s_lds &
   }
 }
 // ... and the pedestrian-free cost terms (one thread): ref :643-666 without the costmap and social terms (left-to-right sum order kept)
-__device__ __forceinline__ void k1s_base_cost(const sfw_launch &L, const k1s_lds &a, const k1s_sample &q, int S) {
+__device__ __forceinline__ double k1s_base_cost_value(const sfw_launch &L, const k1s_lds &a, int S) {
   const double dx = L.ga.wpx - a.xs[S], dy = L.ga.wpy - a.ys[S];
   const double d = dx * dx + dy * dy;
   double ang = atan2(dy, dx) - *a.th_end;
   ang = normalize_angle_f(static_cast<float>(ang), static_cast<float>(-M_PI), static_cast<float>(M_PI));
   ang = fabs(ang) / M_PI;
   const double vel = fabs(L.p.max_vel_x - a.vxs[S - 1]) / L.p.max_vel_x;
-  L.base_cost[q.t] = L.p.vel_weight * vel + L.p.distance_weight * d + L.p.angle_weight * ang;
+  return L.p.vel_weight * vel + L.p.distance_weight * d + L.p.angle_weight * ang;
+}
+__device__ __forceinline__ void k1s_base_cost(const sfw_launch &L, const k1s_lds &a, const k1s_sample &q, int S) {
+  L.base_cost[q.t] = k1s_base_cost_value(L, a, S);
 }
 // (5) footprint: the pose centre must be on the map (ref :545, src/costmap_model.cpp:36-37); K < 3: centre cell
 // only; else every (pose, edge) is a task of its own and a pose's code is the maximum over its tasks
@@ -602,7 +620,9 @@ __device__ __forceinline__ void k1s_footprint(const sfw_launch &L, const k1s_lds
 __device__ __forceinline__ void k1s_quotients(const k1s_lds &a, int S, int tid, int nthr) {
   for (int i = tid; i < S; i += nthr) a.quot[i] = static_cast<double>(a.code[i]) / 255.0;
 }
-__device__ __forceinline__ bool k1s_scan(const sfw_launch &L, const k1s_lds &a, const k1s_sample &q, int S, double *base_out = nullptr) {
+// base_in (nullable): the pedestrian-free cost terms when the caller holds them (else L.base_cost[t], as K1c reads them)
+__device__ __forceinline__ bool k1s_scan(const sfw_launch &L, const k1s_lds &a, const k1s_sample &q, int S, double *base_out = nullptr,
+                                         const double *base_in = nullptr) {
   double cm = 0.0;
   int n_ok = 0;
   bool stopped = false;
@@ -625,7 +645,7 @@ __device__ __forceinline__ bool k1s_scan(const sfw_launch &L, const k1s_lds &a, 
         }
       }
   }
-  return scan_finish(L, q.t, q.local, cm, n_ok, base_out);
+  return scan_finish(L, q.t, q.local, cm, n_ok, base_out, base_in);
 }
 
 __global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const sfw_launch L) {
@@ -637,11 +657,12 @@ __global__ void __launch_bounds__(K1_SMALL_BLOCK) sfw_rollout_small_kernel(const
   const k1s_sample q = k1s_sample_of(L, blockIdx.x);
   const int tid = threadIdx.x, nthr = blockDim.x;
   if (tid == 0) k1s_head(L, q);
-  k1s_velocities(L, a, q, S, tid);
+  k1s_state st = k1s_begin(L, tid);
+  k1s_velocities(L, a, q, 0, S, S, tid, st);
   __syncthreads();
-  k1s_increments(L, a, S, tid, nthr);
+  k1s_increments(L, a, 0, S, tid, nthr);
   __syncthreads();
-  k1s_positions(L, a, S, tid);
+  k1s_positions(L, a, 0, S, tid, st);
   __syncthreads();
   k1s_records<true>(L, a, q, S, tid, nthr);
   if (tid == 0) k1s_base_cost(L, a, q, S);
@@ -2010,13 +2031,24 @@ __device__ __forceinline__ void wave_sync() {
 //   CYCLE = false  sfw_social_kernel_flat: one wave per block, robot records from the K1->K2 table, results by finish_wave;
 //   CYCLE = true   sfw_cycle_kernel (small grids: a control cycle in ONE launch): wave 0 of a block whose other waves roll the
 //                  robot out and check its footprint meanwhile.  The robot's records come from that rollout's LDS arrays
-//                  (`k1`), the block meets once — behind this wave's prologue, when the records are there — and the wave
-//                  hands back its social-work sum and contact verdict instead of writing the cost.
+//                  (`k1`) as they come to stand (cycle_wait_ready), and the wave hands back its social-work sum and contact
+//                  verdict instead of writing the cost.
 // Same statements either way: costs are bit-identical.
 struct cycle_result {
   double social_work;  // lane 0
   int dead;            // 0, or 2 + the step of a pedestrian contact
+  int ready;           // steps whose robot records stand in the block's LDS arrays (written by the wave that rolls the robot out)
+  int fdone;           // waves that have finished their footprint tasks
+  int legal;           // the costmap's verdict (the last of those waves scans the codes)
+  double base0, base;  // pedestrian-free cost terms without / with the costmap term
 };
+// Wait until the robot's records of the first `need` steps stand (sfw_cycle_kernel): a poll of one LDS word, wave-uniform.
+__device__ __forceinline__ int cycle_wait_ready(const cycle_result *res, int need) {
+  int r;
+  while ((r = *const_cast<const volatile int *>(&res->ready)) < need) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return r;
+}
 #define K2_SYNC() do { if constexpr (CYCLE) wave_sync(); else __syncthreads(); } while (0)
 template <typename R, bool GROUPS, int CAP, bool OBS, bool CYCLE>
 __device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *const smem, const k1s_lds *const k1, cycle_result *const res) {
@@ -2219,6 +2251,7 @@ __device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *cons
   // registers.  Without it they are built once: the refresh is ~30 vector instructions per step (the v_mov and the reloads of
   // the scalar constants it pushes out), 1.5 % of a step at the target crowd and 5 % of a lone wave's step with 5 people.
   // (Two kernels, not two loops in one: with both in one function the backend fails — "illegal VGPR to SGPR copy".)
+  [[maybe_unused]] int cyc_ready = 0;  // (CYCLE: steps whose robot records are known to stand)
   for (int step = step_begin; step < step_end; ++step) {
     sfm_consts<R> k = k0;  // the scalar part (15 polynomial coefficients) as built in front of the rollout ...
     if constexpr (OBS) {
@@ -2285,10 +2318,10 @@ __device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *cons
     const late_launch La = late_args();
     const agent_consts c = load_agent_consts(La, F32);
     const sfw_agent_const *const agent_c = La->agent_c;
-    // the cycle kernel's first block barrier, behind the first pair pass (which needs the handed-over state only): the wave
-    // that rolled the robot out has arrived, its records are in LDS
+    // the cycle kernel's hand-over, behind the pair pass (which needs the pre-step state only): the wave that rolls the robot
+    // out publishes how many steps' records stand in LDS — the first few early, then all; a wait is a poll of that word
     if constexpr (CYCLE) {
-      if (step == step_begin) __syncthreads();
+      if (step >= cyc_ready) cyc_ready = cycle_wait_ready(res, step + 1);
     }
     const sfw_robot_step rs = CYCLE ? sfw_robot_step{k1->xs[step + 1], k1->ys[step + 1], k1->vxs[step], k1->vys[step]} : s.rsb[step & 1];
     // (fetched ONE step ahead.  Two steps ahead into a third slot — so that no barrier of a step finds the fetch still in
@@ -2643,13 +2676,16 @@ __global__ void __launch_bounds__(64) sfw_key_table_kernel(const sfw_sel *sel, d
 // ===========================================================================
 // K1 + K2 + K3 of such a grid were three launches back to back (14 + 56 + 5 us at 5 people and 40 steps,
 // profiles/r05_cycle_timeline.txt), each a lone wave per sample waiting for the one before.  Here a sample is one block of
-// four waves, each with a job of its own, and the block meets twice:
-//   wave 0   the pedestrians (social_flat_wave<.., CYCLE>): stages the agents, runs the first pair pass — none of it needs the
-//            robot's trajectory — | barrier 1 | then the rollout, the robot's post-step records read from the LDS arrays
-//            wave 1 has filled (no K1->K2 table, no load in flight across a step);
-//   wave 1   the robot's recurrences (k1s_velocities / _increments / _positions, a wave's worth of lanes) | barrier 1 |
-//   1, 2, 3  Trajectory points, the pedestrian-free cost terms, the footprint tasks (k1s_footprint) — beside the rollout;
-//            | barrier 2 |
+// four waves, each with a job of its own:
+//   wave 0   the pedestrians (social_flat_wave<.., CYCLE>): stages the agents and runs the pair pass of the first step — none
+//            of it needs the robot's trajectory — then the rollout, the robot's post-step records read from the LDS arrays
+//            wave 1 fills (no K1->K2 table, no load in flight across a step).  It waits for a step's record by polling ONE
+//            LDS word (cycle_result.ready), which wave 1 moves as the records come to stand;
+//   wave 1   the robot's recurrences (k1s_velocities / _increments / _positions, a wave's worth of lanes): the first
+//            CYCLE_HEAD steps first — published after ~1 us, so that wave 0 never stands still for the whole rollout — then
+//            the rest;
+//   1, 2, 3  once every pose stands: Trajectory points, the pedestrian-free cost terms, the footprint tasks (k1s_footprint)
+//            — beside the pedestrian rollout;            | the block's one barrier behind all of it |
 //   wave 1   (default FP mode) the in-order costmap scan, the cost = base + w_s x social work, and the selection: the last
 //            block to finish — one atomic counter — reduces the cost vector under the reference's order (sel_consider) and
 //            leaves vector and record in the host's pinned mirror too.
@@ -2657,6 +2693,7 @@ __global__ void __launch_bounds__(64) sfw_key_table_kernel(const sfw_sel *sel, d
 // three-kernel path remains for everything else and as this kernel's checker (tests/test_cycle_kernel_gpu.py: bit-identical).
 constexpr int CYCLE_BLOCK = 4 * WAVE;
 constexpr int CYCLE_MAX_SAMPLES = 1024;
+constexpr int CYCLE_HEAD = 8;  // robot steps handed to the pedestrians' wave ahead of the rest
 template <typename R, bool GROUPS, bool OBS>
 __global__ void __launch_bounds__(CYCLE_BLOCK) sfw_cycle_kernel(const sfw_launch L, const int k2_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K2 wave's area (from LDS address 0) | k1s_lds | cycle_result
@@ -2665,40 +2702,65 @@ __global__ void __launch_bounds__(CYCLE_BLOCK) sfw_cycle_kernel(const sfw_launch
   size_t k1_bytes;
   const k1s_lds a(smem + k2_bytes, S, &k1_bytes);
   cycle_result *const res = reinterpret_cast<cycle_result *>(smem + k2_bytes + k1_bytes);
+  // (the hand-over word starts at 0: written by thread 0, and a block barrier before anybody polls or publishes)
+  if (tid == 0) res->ready = res->fdone = 0;
+  __syncthreads();
   const k1s_sample q = k1s_sample_of(L, blockIdx.x);
   // pedestrians to integrate?  (no agents at all, or a robot alone without a laser point: social work identically 0)
   const bool social = q.scored && L.A > 0 && !(L.A == 1 && L.O == 0 && L.NG == 0);
   if (wave == 0 && social) {
     sfwm::fp_mode_for_omod();
-    social_flat_wave<R, GROUPS, 64, OBS, true>(L, smem, &a, res);  // (holds barrier 1)
+    social_flat_wave<R, GROUPS, 64, OBS, true>(L, smem, &a, res);
   } else {
     if (wave == 1) {
+      // the first CYCLE_HEAD steps first, published to the pedestrians' wave (res->ready) as soon as they stand; then the rest
       if (lane == 0) k1s_head(L, q);
-      k1s_velocities(L, a, q, S, lane);
-      wave_sync();
-      k1s_increments(L, a, S, lane, WAVE);
-      wave_sync();
-      k1s_positions(L, a, S, lane);
+      k1s_state st = k1s_begin(L, lane);
+      for (int i0 = 0; i0 < S;) {
+        const int i1 = i0 == 0 ? min(S, CYCLE_HEAD) : S;
+        k1s_velocities(L, a, q, i0, i1, S, lane, st);
+        wave_sync();
+        k1s_increments(L, a, i0, i1, lane, WAVE);
+        wave_sync();
+        k1s_positions(L, a, i0, i1, lane, st);
+        wave_sync();
+        if (lane == 0) *const_cast<volatile int *>(&res->ready) = i1;  // (the LDS executes this wave's stores in order)
+        i0 = i1;
+      }
+    } else {
+      cycle_wait_ready(res, S);  // the footprint tasks need every pose
     }
-    __syncthreads();  // barrier 1
     const int ftid = social ? tid - WAVE : tid, fn = social ? CYCLE_BLOCK - WAVE : CYCLE_BLOCK;
     k1s_records<false>(L, a, q, S, ftid, fn);
-    if (ftid == fn - 1) k1s_base_cost(L, a, q, S);
-    if (q.scored) k1s_footprint(L, a, S, ftid, fn);
+    if (ftid == fn - 1) res->base0 = k1s_base_cost_value(L, a, S);
+    if (q.scored) {
+      k1s_footprint(L, a, S, ftid, fn);
+      // the LAST of these waves to finish scans the codes in step order (K1c) — beside the pedestrian rollout, not behind it
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      int before = 0;
+      if (lane == 0) before = atomicAdd(&res->fdone, 1);
+      before = __shfl(before, 0, WAVE);
+      if (before == fn / WAVE - 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        k1s_quotients(a, S, lane, WAVE);
+        wave_sync();
+        if (lane == 0) {
+          double base = 0.0;
+          res->legal = k1s_scan(L, a, q, S, &base, &res->base0) ? 1 : 0;
+          res->base = base;
+        }
+      }
+    }
   }
-  __syncthreads();  // barrier 2
+  __syncthreads();  // every wave's part is done
   if (wave != 1) return;
   const int64_t t = q.t;
-  if (q.scored) {
-    k1s_quotients(a, S, lane, WAVE);
-    wave_sync();
-  }
   if (lane == 0) {
     if (!q.scored) {
       if (L.n_points) L.n_points[q.local] = 0;
     } else {
-      double base = 0.0;
-      const bool legal = k1s_scan(L, a, q, S, &base);
+      const double base = res->base;
+      const bool legal = res->legal != 0;
       const int d = social ? res->dead : 0;
       if (legal && L.A > 0) {  // (no agent vector at all: scan_finish has written the cost)
         if (d == 0) {
@@ -3138,7 +3200,7 @@ bool sfw_cycle_applies(const sfw_launch &L) {
   const bool obs_lds = social && obs_in_lds(fl, L.A, L.O, L.NG, L.n_grp_mem, L.chunk_count, L.n_cu > 0 ? L.n_cu : SFW_DEFAULT_CUS);
   size_t k1_bytes = 0;
   (void)k1s_lds(nullptr, L.S, &k1_bytes);
-  return cycle_k2_bytes(L, obs_lds) + k1_bytes + 16 <= 64 * 1024;
+  return cycle_k2_bytes(L, obs_lds) + k1_bytes + ((sizeof(cycle_result) + 15) & ~size_t(15)) <= 64 * 1024;
 }
 template <typename R> static hipError_t launch_cycle_typed(const sfw_launch &L_in, hipStream_t stream) {
   sfw_launch L = L_in;
@@ -3148,7 +3210,7 @@ template <typename R> static hipError_t launch_cycle_typed(const sfw_launch &L_i
   const size_t k2 = cycle_k2_bytes(L, L.k.obs_lds != 0);
   size_t k1_bytes = 0;
   (void)k1s_lds(nullptr, L.S, &k1_bytes);
-  const size_t lds = k2 + k1_bytes + 16;
+  const size_t lds = k2 + k1_bytes + ((sizeof(cycle_result) + 15) & ~size_t(15));
   const dim3 grid(static_cast<unsigned>(L.chunk_count)), block(CYCLE_BLOCK);
   const int k2i = static_cast<int>(k2);
   if (L.NG > 0) hipLaunchKernelGGL((sfw_cycle_kernel<R, true, true>), grid, block, lds, stream, L, k2i);

@@ -28,7 +28,7 @@ for k, label in names.items():
 c5 = ex.get("cfg5_strong")
 if c5:
     rf = c5.get("roofline_frac_rank0", {})
-    rows.append(("cfg5 4096×4096, 100 ped: the whole grid on ONE GPU (six table chunks, 3 timed steps)", c5["value"], c5["ms_per_step"],
+    rows.append((f"cfg5 4096×4096, 100 ped: the whole grid on ONE GPU ({c5.get('chunks_per_gpu', '?')} table chunk(s), {c5.get('steps', '?')} timed steps)", c5["value"], c5["ms_per_step"],
                  c5["per_rank"]["social_kernel_ms"][0], None, rf.get("frac"), rf.get("executed_frac"), "(suite: strided sub-grids)"))
 for k, label in (("f64_strict_mode", "target, `SFW_PRECISION_F64_STRICT`"), ("f32_forces_mode", "target, `SFW_PRECISION_F32`")):
     e = ex.get(k)
