@@ -563,7 +563,7 @@ def host_wait(dist, rank, key):
 
 def measured_traffic(workload_name):
     """HBM bytes per launch from the committed PMC passes (profiles/r0N_traffic.json, newest first), or None."""
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f).get(workload_name)
