@@ -1599,10 +1599,11 @@ template <int FX, int FY> __device__ __forceinline__ void lds_add_pair(uint32_t 
 // the i-side force accumulates in registers, the j-side goes through one LDS
 // atomic whose addresses are all distinct within the instruction.
 // ---------------------------------------------------------------------------
+// What a register-form wave does with its G samples, as the body of two kernels: sfw_social_kernel (every block) and
+// sfw_social_kernel_mixed (its first blocks; the rest run the flat form's body).  bid / nblk: the wave's block index and the
+// block count among the waves of ITS form.
 template <typename R, int NS, bool GROUPS>
-__global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social_kernel(const sfw_launch L, const int G) {
-  sfwm::fp_mode_for_omod();
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void social_reg_wave(const sfw_launch &L, const int G, char *const smem, const unsigned bid, const unsigned nblk) {
   constexpr int CAP = WAVE * NS;  // GA <= CAP: state planes at compile-time distances
   using off = reg_off<CAP>;       // byte offsets from a slot's px word
   constexpr int PY = off::PY, VX = off::VX, VY = off::VY, FJX = off::FJX, FJY = off::FJY;
@@ -1611,7 +1612,7 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   const int GA = G * A;
   const int NG = GROUPS ? L.NG : 0;  // GROUPS=false instantiation: no group code, lean register budget
   const lds_layout s(smem, A, CAP, GA, G, O, NG, GROUPS ? L.n_grp_mem : 0, true, false);
-  const int64_t first_local = static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd))) * G;
+  const int64_t first_local = static_cast<int64_t>(xcd_contiguous(bid, nblk, static_cast<unsigned>(L.n_xcd))) * G;
   const int64_t remain = item_count(L) - first_local;
   const int Gn = remain < G ? static_cast<int>(remain) : G;
   const int step_begin = L.step_begin, step_end = L.step_end;
@@ -1954,6 +1955,12 @@ __global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social
   finish_wave(s, lane, G, Gn, first_local, sw_acc);
   clock_probe(1);
 }
+template <typename R, int NS, bool GROUPS>
+__global__ void __launch_bounds__(WAVE, (NS == 1 && !GROUPS) ? 6 : 1) sfw_social_kernel(const sfw_launch L, const int G) {
+  sfwm::fp_mode_for_omod();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  social_reg_wave<R, NS, GROUPS>(L, G, smem, blockIdx.x, gridDim.x);
+}
 
 // ---------------------------------------------------------------------------
 // K2, flat form (one sample per wave): the A(A-1)/2 unordered pairs are
@@ -2051,7 +2058,8 @@ __device__ __forceinline__ int cycle_wait_ready(const cycle_result *res, int nee
 }
 #define K2_SYNC() do { if constexpr (CYCLE) wave_sync(); else __syncthreads(); } while (0)
 template <typename R, bool GROUPS, int CAP, bool OBS, bool CYCLE>
-__device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *const smem, const k1s_lds *const k1, cycle_result *const res) {
+__device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *const smem, const k1s_lds *const k1, cycle_result *const res,
+                                                 const unsigned bid, const unsigned nblk, const int64_t item_base) {
   const int lane = threadIdx.x;
   const int A = L.A, O = L.O;
   const int NG = GROUPS ? L.NG : 0;
@@ -2061,8 +2069,7 @@ __device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *cons
   (void)FCX;
   (void)FCY;
   const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, GROUPS, true, L.k.obs_lds != 0);
-  const int64_t first_local = CYCLE ? static_cast<int64_t>(blockIdx.x)
-                                    : L.item_base + xcd_contiguous(blockIdx.x, gridDim.x, static_cast<unsigned>(L.n_xcd));
+  const int64_t first_local = CYCLE ? static_cast<int64_t>(bid) : item_base + xcd_contiguous(bid, nblk, static_cast<unsigned>(L.n_xcd));
   const sfm_consts<R> k0 = make_consts<R, true>(L);  // the prologue's; every step builds its own (below)
   // the five force constants stay in scalar registers for the rollout (a step's copy into VGPRs is five v_mov; read from the
   // kernel arguments every step, a lone wave waited for the scalar loads at the top of each)
@@ -2554,7 +2561,27 @@ __global__ void __launch_bounds__(WAVE, (GROUPS || CAP == 0) ? 1 : OBS ? SFW_FLA
   sfwm::fp_mode_for_omod();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   (void)G_unused;
-  social_flat_wave<R, GROUPS, CAP, OBS, false>(L, smem, nullptr, nullptr);
+  social_flat_wave<R, GROUPS, CAP, OBS, false>(L, smem, nullptr, nullptr, blockIdx.x, gridDim.x, L.item_base);
+}
+// Both forms in ONE launch (split_point: a register-form launch whose waves do not divide evenly over the SIMDs hands its last
+// items to flat-form waves): the first n_reg blocks run the register form's body on the first `keep` items, the others the flat
+// form's on the rest.  As two launches on two streams (rounds 4-5, still the way with laser points: the flat form with its
+// laser-point pass needs 96 VGPRs, five waves per SIMD, and could not sit beside five register-form waves) the fork and the join
+// cost ~12 us each on this runtime (profiles/r06_step_timeline_cfg2.txt) — of a 600 us step.  Same bodies: bit-identical.
+template <typename R>
+__global__ void __launch_bounds__(WAVE, 6) sfw_social_kernel_mixed(const sfw_launch L, const int G, const int n_reg, const int keep) {
+  sfwm::fp_mode_for_omod();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.x < static_cast<unsigned>(n_reg)) {
+    // (the register part scores items [0, keep): its item count is read from the launch, so it gets a copy that says so)
+    sfw_launch Lr = L;
+    if (Lr.phase == SFW_PHASE_PREFIX) Lr.n_cls = keep;
+    else Lr.chunk_count = keep;
+    social_reg_wave<R, 1, false>(Lr, G, smem, blockIdx.x, static_cast<unsigned>(n_reg));
+  } else {
+    social_flat_wave<R, false, 64, false, false>(L, smem, nullptr, nullptr, blockIdx.x - static_cast<unsigned>(n_reg),
+                                                 gridDim.x - static_cast<unsigned>(n_reg), keep);
+  }
 }
 
 // ===========================================================================
@@ -2710,7 +2737,7 @@ __global__ void __launch_bounds__(CYCLE_BLOCK) sfw_cycle_kernel(const sfw_launch
   const bool social = q.scored && L.A > 0 && !(L.A == 1 && L.O == 0 && L.NG == 0);
   if (wave == 0 && social) {
     sfwm::fp_mode_for_omod();
-    social_flat_wave<R, GROUPS, 64, OBS, true>(L, smem, &a, res);
+    social_flat_wave<R, GROUPS, 64, OBS, true>(L, smem, &a, res, blockIdx.x, gridDim.x, 0);
   } else {
     if (wave == 1) {
       // the first CYCLE_HEAD steps first, published to the pedestrians' wave (res->ready) as soon as they stand; then the rest
@@ -3028,6 +3055,9 @@ template <int CAP> static bool reg_layout_matches() {
 #ifndef SFW_SPLIT_FORMS
 #define SFW_SPLIT_FORMS 1
 #endif
+#ifndef SFW_MIXED_LAUNCH
+#define SFW_MIXED_LAUNCH 1  // 0: the split launch as two launches on two streams whatever the scan (rounds 4-5; A/B)
+#endif
 static int64_t split_point(const wave_plan &pl, int A, int O, int NG, int form, int64_t items, int cus) {
   if (!SFW_SPLIT_FORMS || form != SFW_K2_AUTO || pl.flat || pl.ns != 1 || A < 2 || A > WAVE || NG > 0) return items;
   const int64_t S = 4LL * cus, W = (items + pl.G - 1) / pl.G, q = W / S;
@@ -3056,6 +3086,17 @@ template <typename R> static hipError_t launch_social_typed(const sfw_launch &L_
   const wave_plan pl = plan_for(L_in.A, items, L_in.O, L_in.k2_form, cus);
   if (sp && sp->side && item_base == 0) {
     const int64_t keep = L_in.pair_tab ? split_point(pl, L_in.A, L_in.O, L_in.NG, L_in.k2_form, items, cus) : items;
+    if (keep < items && L_in.O == 0 && flat_cap(L_in.A) == 64 && SFW_MIXED_LAUNCH) {
+      // both forms in one launch (sfw_social_kernel_mixed): no second stream, no fork, no join
+      const unsigned n_reg = static_cast<unsigned>((keep + pl.G - 1) / pl.G), n_flat = static_cast<unsigned>(items - keep);
+      const wave_plan fl{1, 0, true};
+      const size_t lds = std::max(lds_bytes_for(pl, L_in.A, 0, 0, 0, false), lds_bytes_for(fl, L_in.A, 0, 0, 0, false));
+      sfw_launch L = L_in;
+      L.k.obs_lds = 0;
+      hipLaunchKernelGGL((sfw_social_kernel_mixed<R>), dim3(n_reg + n_flat), dim3(WAVE), lds, stream, L, pl.G, static_cast<int>(n_reg),
+                         static_cast<int>(keep));
+      return hipGetLastError();
+    }
     if (keep < items) {
       // the register-form part first (its waves take their q places per SIMD), the flat part beside it on the other stream
       // (the register-form kernel is left as it is — a bound of its own cost its strict build 36 bytes of scratch —: its part

@@ -60,6 +60,15 @@ def test_flat_form_five_waves_without_scratch(resources):
             assert k["vgpr"] <= 96 and k["scratch"] == 0 and k["occupancy"] >= 5, (cap, obs, k)
 
 
+def test_mixed_launch_kernel_holds_six_waves_per_simd(resources):
+    """sfw_social_kernel_mixed (round 6: a split launch's register-form and flat-form waves in ONE launch, no fork / join across
+    streams) is launched where five register-form waves and one flat-form wave share a SIMD: its allocation is the larger of the
+    two bodies' and must stay within the six-wave budget; a few bytes of scratch (one spilled pair in the flat body's per-step
+    part, measured harmless: profiles/r06_ab_mixed.txt) are tolerated, a stack is not."""
+    k = _kernel(resources, "sfw_social_kernel_mixedId")
+    assert k["vgpr"] <= 80 and k["scratch"] <= 16 and k["occupancy"] >= 6, k
+
+
 # ---- instruction counts of the hot loops, from the ISA (DESIGN.md §3 quotes them; the path is bound by the FP64 operations it
 # issues, so a compiler or source change that adds one shows here before it shows on a GPU) ----
 @pytest.fixture(scope="module")
