@@ -3,7 +3,10 @@
 // whole-cycle medians of  set_costmap + set_footprint + set_agents + score_grid (blocking).
 //
 //   build: make -C social_force_window_planner_amd/csrc latency
-//   run:   build/cycle_latency [cycles] [laser points] [markers]
+//   run:   build/cycle_latency [cycles] [laser points] [markers] [map changes]
+// map changes = 1: one cell of the costmap differs from cycle to cycle (the library recognises an UNCHANGED snapshot and does not
+// send it again: a local costmap updates at its own rate, a few Hz, the controller hands it over at 10-20 Hz); 0 (default): the
+// same map every cycle.
 // markers = 1: every cycle also fetches all 45 Trajectories (what the reference's MarkerArray holds, :347-386) with
 // sfw_set_points_capture on (the scoring launch leaves the points: one extra D2H); markers = 2: the same without the
 // capture (the dump re-runs the rollout).
@@ -29,6 +32,7 @@ int main(int argc, char **argv) {
   const int cycles = argc > 1 ? std::atoi(argv[1]) : 200;
   const int n_laser = argc > 2 ? std::atoi(argv[2]) : 0;  // obstacles1: laser points near the robot
   const int markers = argc > 3 ? std::atoi(argv[3]) : 0;
+  const int map_changes = argc > 4 ? std::atoi(argv[4]) : 0;
   std::vector<double> laser;
   for (int i = 0; i < n_laser; ++i) {  // a wall 1.5 m to the left and a pillar ahead
     const double u = (i + 0.5) / n_laser;
@@ -80,6 +84,7 @@ int main(int argc, char **argv) {
       std::vector<int32_t> npts(45);
       if (markers == 1) sfw_set_points_capture(h, 1);
       for (int c = 0; c < cycles + 10; ++c) {
+        if (map_changes) cells[static_cast<size_t>(N) * 7 + 7 + (c % 5)] = static_cast<uint8_t>(c & 1);  // (a free cell far from the robot)
         const auto t0 = clk::now();
         int rc = sfw_set_costmap(h, cells.data(), N, N, origin, origin, res);
         const double a = us_since(t0);

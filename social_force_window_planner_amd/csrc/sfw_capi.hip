@@ -113,6 +113,9 @@ struct sfw_planner_s {
     uint32_t size_x, size_y;
     double origin_x, origin_y, resolution;
   } map_new{0, 0, 0, 0, 0};             // what sfw_set_costmap handed over last (pin_map holds its cells)
+  bool arena_pending = false;           // the last stage left its arena in pin_world only (see stage_common / flush_arena)
+  size_t arena_from = 0, arena_bytes = 0;
+  bool arena_direct_on = true;          // SFW_ARENA_DIRECT=0 in the environment of sfw_create: always copy at stage time
   bool cells_dirty = false;             // ... and the device has not seen yet
   bool cells_in_world = false;          // the device copy is the head of `world` (small maps), else `cells`
   size_t world_cells_bytes = 0;         // bytes of that head
@@ -377,6 +380,9 @@ void fill_launch(sfw_handle h, sfw_launch &L, int64_t begin, int64_t count, int6
   L.sel_out = h->d_sel;
   L.costs_host = nullptr;
   L.sel_host = nullptr;
+  L.arena_host = nullptr;
+  L.arena_dev = nullptr;
+  L.arena_bytes = 0;
 }
 
 // ---- shared-prefix plan ---------------------------------------------------
@@ -1150,11 +1156,21 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
     ph.mark("pack");
     {
       const size_t from = send_cells ? 0 : cells_head;
-      SFW_HIP(h, hipMemcpyAsync(h->world.p + from, pb + from, total - from, hipMemcpyHostToDevice, h->stream));
+      // A control cycle's grid whose costmap has not changed: no copy here.  If the launch turns out to be the one-launch kernel
+      // its blocks read the (~1 KB) arena from this pinned memory themselves; else the launch enqueues the copy (flush_arena).
+      h->arena_pending = false;
+      if (grid && h->arena_direct_on && from == cells_head && static_cast<int64_t>(nv) * nw <= 1024 && total - from <= (size_t(16) << 10) &&
+          (total - from) % 16 == 0) {
+        h->arena_pending = true;
+        h->arena_from = from;
+        h->arena_bytes = total - from;
+      } else {
+        SFW_HIP(h, hipMemcpyAsync(h->world.p + from, pb + from, total - from, hipMemcpyHostToDevice, h->stream));
+      }
     }
     h->d_cells = merge ? reinterpret_cast<const uint8_t *>(h->world.p) : h->cells.p;
     ph.mark("h2d");
-    SFW_HIP(h, h->pin_world.mark(h->stream));
+    if (!h->arena_pending) SFW_HIP(h, h->pin_world.mark(h->stream));
     ph.mark("evrec");
     const char *db = h->world.p;
     h->d_cls_tab = h->cls_ints.empty() ? nullptr : reinterpret_cast<const int32_t *>(db + o_cls);
@@ -1198,11 +1214,23 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   return SFW_OK;
 }
 
+// The arena a stage left in pinned memory only (arena_pending) goes to the device by a copy after all: the launch is not the
+// one-launch kernel, or something is about to patch the device copy.
+int flush_arena(sfw_handle h) {
+  if (!h->arena_pending) return SFW_OK;
+  h->arena_pending = false;
+  SFW_HIP(h, hipMemcpyAsync(h->world.p + h->arena_from, h->pin_world.p + h->arena_from, h->arena_bytes, hipMemcpyHostToDevice, h->stream));
+  SFW_HIP(h, h->pin_world.mark(h->stream));
+  return SFW_OK;
+}
+
 int launch_common(sfw_handle h) {
   if (!h) return SFW_ERR_INVALID_ARG;
   if (!h->staged) return fail(h, SFW_ERR_STATE, "grid_launch before grid_stage");
   SFW_HIP(h, hipSetDevice(h->device));
   const int64_t T = static_cast<int64_t>(h->nv) * h->nw;
+  if (h->plan_epoch != h->params_epoch)
+    if (int e = flush_arena(h)) return e;  // (the re-plan below patches the device copy of the rest terms)
   // sfw_set_params since the stage: tables and shared-prefix plan are redone for the live parameters
   if (h->plan_epoch != h->params_epoch) {
     if (int e = replan_at_launch(h)) return e;  // (also drops the poses the stage started: they were rolled out under the old parameters)
@@ -1306,7 +1334,16 @@ int launch_common(sfw_handle h) {
     L.sel_host = sel_host;
     if (sfw_cycle_applies(L)) {
       if (timing) SFW_HIP(h, hipEventRecord(h->ev[1], h->stream));  // (no K1 of its own: K1 time 0, the launch is "K2")
+      if (h->arena_pending) {  // the kernel's blocks fetch the arena from pinned memory themselves: no copy at all this cycle
+        L.arena_host = h->pin_world.p + h->arena_from;
+        L.arena_dev = h->world.p + h->arena_from;
+        L.arena_bytes = static_cast<uint32_t>(h->arena_bytes);
+      }
       SFW_HIP(h, h->params.precision == SFW_PRECISION_F64_STRICT ? sfw_launch_cycle_strict(L, h->stream) : sfw_launch_cycle(L, h->stream));
+      if (h->arena_pending) {
+        h->arena_pending = false;
+        SFW_HIP(h, h->pin_world.mark(h->stream));
+      }
       if (timing) {
         SFW_HIP(h, hipEventRecord(h->ev[2], h->stream));
         SFW_HIP(h, hipEventRecord(h->ev[3], h->stream));
@@ -1318,6 +1355,7 @@ int launch_common(sfw_handle h) {
     }
   }
   h->launched_cycle = false;
+  if (int e = flush_arena(h)) return e;
   int c = 0;
   for (int64_t b = 0; b < T; b += chunk, ++c) {
     const int64_t n = (T - b < chunk) ? (T - b) : chunk;
@@ -1496,6 +1534,7 @@ int sfw_create(const sfw_params *params, int device, sfw_handle *out) {
   if (const char *b = std::getenv("SFW_FORCE_FLAT")) h->k2_form = std::atoi(b) == 1 ? SFW_K2_FLAT : std::atoi(b) == 0 ? SFW_K2_REGISTER : SFW_K2_AUTO;
   if (const char *b = std::getenv("SFW_PIN_REST")) h->pin_rest_on = std::atoi(b) != 0;
   if (const char *b = std::getenv("SFW_SPIN_US")) h->spin_us = std::max(0L, std::atol(b));
+  if (const char *b = std::getenv("SFW_ARENA_DIRECT")) h->arena_direct_on = std::atoi(b) != 0;
   if (const char *b = std::getenv("SFW_MIRROR_MAX_MB")) h->mirror_max_bytes = static_cast<size_t>(std::max(0L, std::atol(b))) << 20;
   if (const char *b = std::getenv("SFW_OBS_TASKS")) h->obs_tasks_force = std::atoi(b) != 0 ? 1 : 0;
   if (const char *b = std::getenv("SFW_TABLE_BUDGET_MB")) {
@@ -1612,6 +1651,12 @@ int sfw_set_costmap(sfw_handle h, const uint8_t *cells, uint32_t size_x, uint32_
   // The snapshot is taken here (the caller's buffer may change on return) and reaches the device with the NEXT stage — like
   // footprint and agents — as part of that stage's one arena copy when it is small (a control cycle's local costmap: one
   // copy per cycle instead of two with the host's call-to-call latency between them), by a copy of its own otherwise.
+  // (an unchanged snapshot — a controller hands its local costmap over every cycle, the map changes at the costmap's own
+  // rate — is recognised here, ~1 us for 40 KB, and not sent again)
+  if (h->have_costmap && h->pin_map.p && n <= h->pin_map.cap && h->map_new.size_x == size_x && h->map_new.size_y == size_y &&
+      h->map_new.origin_x == origin_x && h->map_new.origin_y == origin_y && h->map_new.resolution == resolution &&
+      std::memcmp(h->pin_map.p, cells, n) == 0)
+    return SFW_OK;
   SFW_HIP(h, h->pin_map.reserve(n));  // (waits for a copy out of it that is still pending)
   std::memcpy(h->pin_map.p, cells, n);
   h->map_new = {size_x, size_y, origin_x, origin_y, resolution};

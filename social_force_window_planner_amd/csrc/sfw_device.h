@@ -204,6 +204,12 @@ struct sfw_launch {
   sfw_sel *sel_out;         // the selection record (device)
   double *costs_host;       // nullable: pinned mirror of the cost vector ...
   sfw_sel *sel_host;        // ... and of the record
+  // sfw_cycle_kernel only, nullable: the stage's arena (footprint | agents | sample vectors | ...) has NOT been copied to the
+  // device; every block copies it from the host's pinned memory to arena_dev itself, in front of everything else (all blocks
+  // write the same bytes).  A control cycle whose costmap has not changed is then ONE kernel and no copy at all.
+  const char *arena_host;
+  char *arena_dev;
+  uint32_t arena_bytes;
 };
 
 

@@ -2729,6 +2729,16 @@ __global__ void __launch_bounds__(CYCLE_BLOCK) sfw_cycle_kernel(const sfw_launch
   size_t k1_bytes;
   const k1s_lds a(smem + k2_bytes, S, &k1_bytes);
   cycle_result *const res = reinterpret_cast<cycle_result *>(smem + k2_bytes + k1_bytes);
+  // the stage's arena straight from the host's pinned memory (sfw_launch.arena_host: no H2D copy was enqueued for it): 16
+  // bytes per thread and round, one PCIe round trip for a control cycle's ~1 KB; every block writes the same bytes, and reads
+  // them back behind the barrier below
+  if (L.arena_host) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *const src = reinterpret_cast<const u32x4 *>(L.arena_host);
+    u32x4 *const dst = reinterpret_cast<u32x4 *>(L.arena_dev);
+    for (uint32_t u = tid; u < L.arena_bytes / 16; u += CYCLE_BLOCK) dst[u] = __builtin_nontemporal_load(src + u);
+    __threadfence();
+  }
   // (the hand-over word starts at 0: written by thread 0, and a block barrier before anybody polls or publishes)
   if (tid == 0) res->ready = res->fdone = 0;
   __syncthreads();

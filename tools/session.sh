@@ -34,7 +34,8 @@ timeline)
   bash tools/step_timeline.sh ${1:-cfg2} > $OUT/${TAG}_step_timeline_${1:-cfg2}.txt 2>&1; cat $OUT/${TAG}_step_timeline_${1:-cfg2}.txt ;;
 cycle)
   N=${1:-300}
-  { for o in 0 60 240; do echo "== build/cycle_latency $N $o"; build/cycle_latency $N $o; done
+  { for o in 0 60 240; do echo "== build/cycle_latency $N $o (the same costmap every cycle: not re-sent)"; build/cycle_latency $N $o; done
+    for o in 0 60; do echo "== build/cycle_latency $N $o 0 1 (the costmap changes every cycle: one H2D copy per cycle)"; build/cycle_latency $N $o 0 1; done
     echo "== build/cycle_latency $N 0 1 (marker capture)"; build/cycle_latency $N 0 1
     echo "== SFW_CYCLE_FUSED=0 (three launches per cycle) build/cycle_latency $N 0"; SFW_CYCLE_FUSED=0 build/cycle_latency $N 0
     echo "== SFW_CYCLE_FUSED=0 build/cycle_latency $N 60"; SFW_CYCLE_FUSED=0 build/cycle_latency $N 60; } > $OUT/${TAG}_latency.txt 2>&1
