@@ -992,7 +992,18 @@ int plan_tables_device(sfw_handle h, int64_t chunk, bool may_start_poses) {
       }
       if (h->timing) SFW_HIP(h, hipEventRecord(h->ev[0], h->stream));
       h->early_poses_timed = h->timing;
+      if (h->arena_pending) {  // no copy was enqueued: this kernel fetches the arena, and reads its sample vectors at their host addresses
+        L.arena_host = h->pin_world.p + h->arena_from;
+        L.arena_dev = h->world.p + h->arena_from;
+        L.arena_bytes = static_cast<uint32_t>(h->arena_bytes);
+        L.linvels = reinterpret_cast<const double *>(h->pin_world.p + (reinterpret_cast<const char *>(h->d_linvels) - h->world.p));
+        L.angvels = reinterpret_cast<const double *>(h->pin_world.p + (reinterpret_cast<const char *>(h->d_angvels) - h->world.p));
+      }
       SFW_HIP(h, sfw_launch_rollout_poses(L, h->stream));
+      if (h->arena_pending) {
+        h->arena_pending = false;
+        SFW_HIP(h, h->pin_world.mark(h->stream));
+      }
       h->early_poses = true;
     }
   }
@@ -1056,6 +1067,8 @@ struct host_phases {
     if (on) std::fprintf(stderr, "[sfw] %s us\n", out.c_str());
   }
 };
+
+int flush_arena(sfw_handle h);
 
 int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int32_t nv, const double *ang,
                  int32_t nw, const sfw_goal_args *args, double vy_samp, int skip_zero, int64_t index_base,
@@ -1159,8 +1172,12 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
       // A control cycle's grid whose costmap has not changed: no copy here.  If the launch turns out to be the one-launch kernel
       // its blocks read the (~1 KB) arena from this pinned memory themselves; else the launch enqueues the copy (flush_arena).
       h->arena_pending = false;
-      if (grid && h->arena_direct_on && from == cells_head && static_cast<int64_t>(nv) * nw <= 1024 && total - from <= (size_t(16) << 10) &&
-          (total - from) % 16 == 0) {
+      // ... and a GPU-filling single-chunk grid: the pose rollout this stage enqueues below (plan_tables_device) fetches the
+      // arena — with a small costmap that has changed, if any — itself, its thousands of threads 16 bytes each
+      const int64_t T_ = static_cast<int64_t>(nv) * nw;
+      const bool small = T_ <= 1024 && from == cells_head && total - from <= (size_t(16) << 10);
+      const bool early = T_ > 2048 && chunk >= T_ && total - from <= (size_t(1) << 20);
+      if (grid && h->arena_direct_on && (small || early) && (total - from) % 16 == 0 && from % 16 == 0) {
         h->arena_pending = true;
         h->arena_from = from;
         h->arena_bytes = total - from;
@@ -1208,6 +1225,8 @@ int stage_common(sfw_handle h, const sfw_robot_state *rs, const double *lin, int
   SFW_HIP(h, h->partials.reserve(sfw_argmin_partials(T)));
   ph.mark("reserve");
   if (int e = plan_tables_device(h, chunk, grid)) return e;
+  if (T > 1024)
+    if (int e = flush_arena(h)) return e;  // (no pose rollout was enqueued after all: the copy it would have stood in for)
   ph.mark("tables+K1a");
   h->staged = true;
   h->launched = false;

@@ -261,8 +261,21 @@ __device__ __forceinline__ bool scan_finish(const sfw_launch &L, int64_t t, int6
 __device__ __forceinline__ void clear_clock_probe(const sfw_launch &L) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && L.clock_probe) L.clock_probe[0] = L.clock_probe[1] = L.clock_probe[2] = L.clock_probe[3] = 0ull;
 }
+// The stage's arena from the host's pinned memory to its place on the device, by the kernel that runs first in a GPU-filling
+// launch (sfw_launch.arena_host: the stage enqueued no H2D copy): 16 bytes per thread, the whole grid's threads side by side —
+// one round for a target-sized arena.  This kernel itself reads its sample vectors through the host addresses it was given
+// (L.linvels / L.angvels point into the pinned arena for this launch); every later kernel reads the device copy.
+__device__ __forceinline__ void fetch_arena(const sfw_launch &L) {
+  if (!L.arena_host) return;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 *const src = reinterpret_cast<const u32x4 *>(L.arena_host);
+  u32x4 *const dst = reinterpret_cast<u32x4 *>(L.arena_dev);
+  const uint32_t n = L.arena_bytes / 16, stride = gridDim.x * blockDim.x;
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride) dst[u] = __builtin_nontemporal_load(src + u);
+}
 __global__ void __launch_bounds__(64) sfw_rollout_kernel(const sfw_launch L) {
   clear_clock_probe(L);
+  fetch_arena(L);
   const int64_t local = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (local >= L.chunk_count) return;
   rollout_sample(L, local);
@@ -284,6 +297,7 @@ constexpr int K1A_TEAM = 8;
 __global__ void __launch_bounds__(64) sfw_rollout_team_kernel(const sfw_launch L) {
   constexpr int TEAMS = WAVE / K1A_TEAM;
   clear_clock_probe(L);
+  fetch_arena(L);
   __shared__ double r_th[TEAMS][K1A_TEAM], r_vx[TEAMS][K1A_TEAM], r_vy[TEAMS][K1A_TEAM];  // [team][step of the round]
   __shared__ double2 r_inc[TEAMS][K1A_TEAM];
   __shared__ double r_px[TEAMS][K1A_TEAM + 1], r_py[TEAMS][K1A_TEAM + 1];                  // pose before step q; [nst]: after the round
