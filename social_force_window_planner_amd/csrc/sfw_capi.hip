@@ -2037,6 +2037,7 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
   if (first < 0 || count <= 0 || first + count > T || !points_xyth || !n_points)
     return fail(h, SFW_ERR_INVALID_ARG, "grid_points: bad range or buffer");
   SFW_HIP(h, hipSetDevice(h->device));
+  if (int e = flush_arena(h)) return e;  // (a dump between stage and launch: the re-run below reads the device copy of the arena)
   const int S = num_steps_of(h->params);
   const size_t n = static_cast<size_t>(count);
   if (h->launched && h->captured && h->cap_S == S) {  // (sfw_set_params since the launch changed the step count: re-run below)

@@ -146,3 +146,24 @@ def test_a_control_cycle_without_any_copy(hip_mod, monkeypatch):
     for (ca, ba), (cb, bb) in zip(a, b):
         assert _same(ca, cb) and ba == bb
     assert not _same(a[0][0], a[2][0])
+
+
+def test_a_points_dump_between_stage_and_launch(hip_mod):
+    """sfw_grid_points_batch needs only a staged grid; with the arena still in pinned memory only (a control cycle's stage
+    enqueues no copy) the dump must send it first.  Same points as after the launch, and the launch still scores the same."""
+    w = dataclasses.replace(syn.WORKLOADS["ref5x9"], n_people=6, seed=52)
+    scene = syn.make_scene(w)
+    g = hip_mod.HipScorer(_params(w))
+    g.load_scene(scene)
+    ref_costs, ref_best = g.score_grid(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    ref_pts, ref_n = g.grid_points_batch(0, 45, w.n_steps)
+    g2 = hip_mod.HipScorer(_params(w))
+    g2.load_scene(scene)
+    g2.stage(scene.robot_state, scene.linvels, scene.angvels, scene.goal_args)
+    pts, n = g2.grid_points_batch(0, 45, w.n_steps)     # before any launch: point counts lack the pedestrian contacts only
+    assert _same(pts[:, 0, :], ref_pts[:, 0, :]) and np.all(n >= ref_n)
+    g2.launch()
+    costs, best, _ = g2.fetch()
+    assert _same(costs, ref_costs) and best == ref_best
+    pts, n = g2.grid_points_batch(0, 45, w.n_steps)
+    assert np.array_equal(n, ref_n) and _same(pts, ref_pts)
