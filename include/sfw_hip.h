@@ -187,8 +187,12 @@ int sfw_set_params(sfw_handle h, const sfw_params *params);
 const char *sfw_last_error(sfw_handle h);
 
 /* ---- world state (replaces const Costmap2D& / footprint_spec_ / getAgents) */
-/* cells: row-major, y outer, cells[my*size_x+mx] == Costmap2D::getCost(mx,my).
- * Snapshot copy (the reference reads nav2's live costmap, sfw_planner.hpp:362). */
+/* The three calls snapshot their arguments on the host (the caller's buffers may change on return); what has changed
+ * reaches the device with the NEXT sfw_grid_stage / sfw_score_* — a launch of a grid staged before the call still
+ * scores the old state.
+ * cells: row-major, y outer, cells[my*size_x+mx] == Costmap2D::getCost(mx,my) (the reference reads nav2's live
+ * costmap, sfw_planner.hpp:362).  A snapshot whose cells and geometry equal the last one's is recognised (a memcmp)
+ * and not sent again: hand the live map over every cycle. */
 int sfw_set_costmap(sfw_handle h, const uint8_t *cells, uint32_t size_x,
                     uint32_t size_y, double origin_x, double origin_y,
                     double resolution);
