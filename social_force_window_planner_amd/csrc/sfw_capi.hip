@@ -275,14 +275,22 @@ bool all_finite(const double *v, size_t n) {
 hipError_t wait_stream(sfw_handle h) {
   if (h->spin_us > 0) {
     const auto t0 = std::chrono::steady_clock::now();
+    bool polled = false;
     for (;;) {
       const hipError_t e = hipStreamQuery(h->stream);
-      if (e != hipErrorNotReady) return e;
+      if (e != hipErrorNotReady) {
+        // ("not ready" is an answer, not an error: a runtime that records it as the thread's last error must not hand it to the
+        // next launch's hipGetLastError)
+        if (polled && e == hipSuccess) (void)hipGetLastError();
+        return e;
+      }
+      polled = true;
       if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > h->spin_us) break;
 #if defined(__x86_64__)
       __builtin_ia32_pause();
 #endif
     }
+    (void)hipGetLastError();
   }
   return hipStreamSynchronize(h->stream);
 }
