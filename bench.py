@@ -6,12 +6,18 @@ path on MI355X.
 
 One "step" = one BLOCKING scoring call through the C ABI, as SURVEY.md §8d defines the
 metric (the reference's grid loop is one blocking loop, src/sfw_planner.cpp:345-417):
-sfw_grid_stage (shared-prefix planning on the host + ONE H2D copy of footprint, agents and
-the sample vectors) + sfw_grid_launch (K1a/K1b/K1c, the K2 dispatches, K3) + sfw_grid_fetch
-(D2H of the 8*T-byte cost vector and the selection, stream sync) — the three calls
-sfw_score_grid is made of.  The world state (costmap, footprint, agents) is resident in the
+sfw_grid_stage (shared-prefix planning on the host, the arena of footprint, agents, sample
+vectors and class tables packed in pinned memory — the launch's first kernel fetches it) +
+sfw_grid_launch (K1a/K1b/K1c, the K2 dispatches, K3) + sfw_grid_fetch (wait for the stream;
+the 8*T-byte cost vector and the selection are on the host when it returns, written there by
+the selection kernels and read in place through sfw_grid_costs_view) — the three calls
+sfw_score_grid is made of, their arguments marshalled once (HipScorer.prepared).  The world state (costmap, footprint, agents) is resident in the
 library before the timed region starts.  Default workload: the north-star target
 configuration (256 x 256 samples, 50 pedestrians, 40 steps).
+
+`--gpus N` MEANS N ranks, one per GPU: under the driver's `torch.distributed.run` it checks WORLD_SIZE == N; started on its own it
+re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (ensure_ranks); a mismatch, or fewer
+devices than ranks over RCCL, exits 2 and prints no line.
 
 N > 1 (one process per GPU under torch.distributed.run): the ranks share an N-times taller
 grid (weak scaling; rows are the outer, sharded axis, ref :345) — contiguous blocks of linvel
