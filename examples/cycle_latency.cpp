@@ -105,10 +105,19 @@ int main(int argc, char **argv) {
           t_mark.push_back(f - e);
         }
       }
+      // the scalar call sites (ref :204-206 rotate in place, :299-301): one blocking sfw_score_one with its Trajectory points
+      std::vector<double> t_one;
+      for (int c = 0; c < 60; ++c) {
+        double cost = 0;
+        int32_t np = 0;
+        const auto t0 = clk::now();
+        if (sfw_score_one(h, &rs, 0.0, 0.0, 0.4, &ga, &cost, pts.data(), S, &np) != SFW_OK) return 1;
+        if (c >= 10) t_one.push_back(us_since(t0));
+      }
       std::printf("N=%2d O=%3d S=%2d: cycle %6.1f us  (set_costmap %5.1f  set_footprint %4.1f  set_agents %5.1f  score_grid %6.1f",
                   n_people, n_laser, S, median(t_all), median(t_map), median(t_fp), median(t_ag), median(t_score));
       if (markers) std::printf("  points of 45 samples %5.1f [%s]", median(t_mark), markers == 1 ? "captured" : "re-run");
-      std::printf(")  best index %lld\n", static_cast<long long>(best.index));
+      std::printf(")  best index %lld  | score_one %5.1f us\n", static_cast<long long>(best.index), median(t_one));
       sfw_destroy(h);
     }
   return 0;

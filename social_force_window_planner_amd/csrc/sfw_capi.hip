@@ -230,6 +230,7 @@ struct sfw_planner_s {
   uint64_t params_epoch = 1, plan_epoch = 0;
   size_t table_budget_bytes = size_t(8) << 30;  // K1->K2 per-step tables per chunk (of 288 GB): BASELINE cfg4 runs in one chunk
   pinned_buf pin_map, pin_world, pin_out, pin_cls;
+  pinned_buf pin_one;     // sfw_score_one's outputs where the one-launch kernel writes them (cost | n_points | coll_step | points)
   pinned_buf pin_mirror;  // costs + selection record as the selection kernels of the last launch leave them (device writes)
 };
 
@@ -1640,6 +1641,7 @@ int sfw_destroy(sfw_handle h) {
   h->pin_world.release();
   h->pin_out.release();
   h->pin_mirror.release();
+  h->pin_one.release();
   h->pin_cls.release();
   h->d_cls.release();
   for (auto &b : h->cls_dead) b.release();
@@ -1857,9 +1859,55 @@ int sfw_score_one(sfw_handle h, const sfw_robot_state *rs, double vx_samp, doubl
                   int32_t *n_points) {
   if (!h) return SFW_ERR_INVALID_ARG;
   if (!cost_out) return fail(h, SFW_ERR_INVALID_ARG, "score_one: cost_out is NULL");
-  if (int e = stage_common(h, rs, &vx_samp, 1, &vtheta_samp, 1, args, vy_samp, 0, 0)) return e;
+  if (int e = stage_common(h, rs, &vx_samp, 1, &vtheta_samp, 1, args, vy_samp, 0, 0, true)) return e;
   if (int e = check_lds(h, 1)) return e;
   const int S = num_steps_of(h->params);
+  {
+    // The latency path (called on every approach / rotate cycle, ref :204-206, :299-301) as ONE launch and no copy: the
+    // one-launch kernel with its outputs — cost, point count, contact step, Trajectory points — in pinned host memory, the
+    // stage's arena fetched by the kernel (stage_common left it pending), no selection.
+    const size_t head = 16, pts_bytes = sizeof(double) * 3 * static_cast<size_t>(S);
+    sfw_launch L;
+    fill_launch(h, L, 0, 1, 1);
+    L.sel_out = nullptr;
+    L.cycle_counter = nullptr;
+    const bool want_pts = (points_xyth && points_cap > 0) || n_points;
+    L.force_alive = want_pts ? 1 : 0;
+    if (sfw_cycle_applies(L)) {
+      if (head + pts_bytes > h->pin_one.cap) SFW_HIP(h, hipStreamSynchronize(h->stream));  // (growing it frees the old area)
+      SFW_HIP(h, h->pin_one.reserve(head + pts_bytes));
+      L.costs = reinterpret_cast<double *>(h->pin_one.p);
+      L.n_points = reinterpret_cast<int32_t *>(h->pin_one.p + 8);
+      L.coll_step = reinterpret_cast<int32_t *>(h->pin_one.p + 12);
+      L.points = reinterpret_cast<double *>(h->pin_one.p + head);
+      if (h->arena_pending) {
+        L.arena_host = h->pin_world.p + h->arena_from;
+        L.arena_dev = h->world.p + h->arena_from;
+        L.arena_bytes = static_cast<uint32_t>(h->arena_bytes);
+      }
+      SFW_HIP(h, h->params.precision == SFW_PRECISION_F64_STRICT ? sfw_launch_cycle_strict(L, h->stream) : sfw_launch_cycle(L, h->stream));
+      if (h->arena_pending) {
+        h->arena_pending = false;
+        SFW_HIP(h, h->pin_world.mark(h->stream));
+      }
+      SFW_HIP(h, wait_stream(h));
+      stream_is_idle(h);
+      int32_t n = 0, coll = -1;
+      std::memcpy(cost_out, h->pin_one.p, sizeof(double));
+      std::memcpy(&n, h->pin_one.p + 8, sizeof(n));
+      std::memcpy(&coll, h->pin_one.p + 12, sizeof(coll));
+      if (coll >= 0 && coll + 1 < n) n = coll + 1;  // rejected by contact at step `coll`: poses 0..coll were added
+      if (n_points) *n_points = n;
+      if (points_xyth && points_cap > 0 && n > 0) {
+        const int m = n < points_cap ? n : points_cap;
+        std::memcpy(points_xyth, h->pin_one.p + head, sizeof(double) * 3 * static_cast<size_t>(m));
+      }
+      h->staged = false;  // score_one clobbers the staged grid
+      h->launched = false;
+      return SFW_OK;
+    }
+    if (int e = flush_arena(h)) return e;  // the three-kernel path below reads the device copy
+  }
   // cost (8) | n_points (4) | coll_step (4) | points (24 S): contiguous on the device, so the latency path
   // (called on every approach / rotate cycle, ref :204-206, :299-301) pays one pinned D2H, like sfw_grid_fetch
   const size_t head = 16, pts_bytes = sizeof(double) * 3 * static_cast<size_t>(S);

@@ -2826,7 +2826,8 @@ __global__ void __launch_bounds__(CYCLE_BLOCK) sfw_cycle_kernel(const sfw_launch
       }
     }
   }
-  // ---- selection by the last block to get here
+  // ---- selection by the last block to get here (a launch without a selection record — sfw_score_one's one sample — ends here)
+  if (!L.sel_out) return;
   __threadfence();
   unsigned prev = 0;
   if (lane == 0) prev = atomicAdd(L.cycle_counter, 1u);
@@ -3255,7 +3256,7 @@ bool sfw_cycle_applies(const sfw_launch &L) {
   if (const char *e = std::getenv("SFW_CYCLE_FUSED"))
     if (e[0] == '0') return false;
   if (L.phase != SFW_PHASE_WHOLE || L.resume || L.chunk_begin != 0 || L.chunk_count <= 0 || L.chunk_count > CYCLE_MAX_SAMPLES) return false;
-  if (L.S > K1_SMALL_MAX_STEPS || !L.cycle_counter || !L.sel_out) return false;
+  if (L.S > K1_SMALL_MAX_STEPS || (L.sel_out && !L.cycle_counter)) return false;
   const bool social = L.A > 0 && !(L.A == 1 && L.O == 0 && L.NG == 0);
   if (social) {
     const int cus = L.n_cu > 0 ? L.n_cu : SFW_DEFAULT_CUS;
