@@ -180,8 +180,7 @@ struct sfw_planner_s {
   bool early_poses_timed = false;  // ... and the stage recorded ev[0] in front of it (timing was on at stage time)
   bool capture_points = false, captured = false;
   int cap_S = 0;                 // step count the capturing launch ran with (the dump's layout)
-  dev_buf<char> cap;             // points (24 S T bytes) | n_points (4 T) | contact steps (4 T)
-  pinned_buf pin_cap;
+  pinned_buf pin_cap;            // points (24 S T bytes) | n_points (4 T) | contact steps (4 T), written by the capturing launch
 
   // shared-prefix plan of the staged grid (sfw_device.h: sfw_cls_agent); no levels: not used
   struct level_tables {               // offsets (ints) into d_cls
@@ -1324,8 +1323,11 @@ int launch_common(sfw_handle h) {
     fill_launch(h, probe, 0, T, chunk);
     if (sfw_rollout_is_fused(probe)) {
       const size_t pts_bytes = sizeof(double) * 3 * static_cast<size_t>(S) * static_cast<size_t>(T);
-      SFW_HIP(h, h->cap.reserve(pts_bytes + 8 * static_cast<size_t>(T)));
-      cap_pts = h->cap.p;
+      // (in pinned HOST memory: the kernels write points, counts and contact steps over PCIe as they go — 43 KB for 45 samples
+      // of 40 steps — and the dump is a memcpy; until round 5 a device buffer and a D2H copy per dump, 12 us)
+      if (pts_bytes + 8 * static_cast<size_t>(T) > h->pin_cap.cap) SFW_HIP(h, hipStreamSynchronize(h->stream));
+      SFW_HIP(h, h->pin_cap.reserve(pts_bytes + 8 * static_cast<size_t>(T)));
+      cap_pts = h->pin_cap.p;
       cap_n = cap_pts + pts_bytes;
       cap_coll = cap_n + 4 * static_cast<size_t>(T);
       h->captured = true;
@@ -1625,7 +1627,6 @@ int sfw_destroy(sfw_handle h) {
   h->partials.release();
   h->clock.release();
   h->cycle_counter.release();
-  h->cap.release();
   h->pin_cap.release();
   h->points.release();
   h->n_points.release();
@@ -1834,6 +1835,7 @@ int sfw_grid_fetch(sfw_handle h, double *costs_out, sfw_best *best_out, sfw_best
     SFW_HIP(h, hipMemcpyAsync(h->pin_out.p, src, cost_bytes + sizeof(sfw_sel), hipMemcpyDeviceToHost, h->stream));
     SFW_HIP(h, wait_stream(h));
     stream_is_idle(h);
+    h->fetched = true;
     if (costs_out) std::memcpy(costs_out, h->pin_out.p, cost_bytes);
     std::memcpy(&s, h->pin_out.p + cost_bytes, sizeof(s));
   }
@@ -2097,11 +2099,13 @@ int sfw_grid_points_batch(sfw_handle h, int64_t first, int64_t count, double *po
   const int S = num_steps_of(h->params);
   const size_t n = static_cast<size_t>(count);
   if (h->launched && h->captured && h->cap_S == S) {  // (sfw_set_params since the launch changed the step count: re-run below)
-    // the scoring launch left everything (sfw_set_points_capture): ONE copy of points | counts | contact steps, no kernel
-    const size_t pts_bytes = sizeof(double) * 3 * static_cast<size_t>(S) * static_cast<size_t>(T), total = pts_bytes + 8 * static_cast<size_t>(T);
-    SFW_HIP(h, h->pin_cap.reserve(total));
-    SFW_HIP(h, hipMemcpyAsync(h->pin_cap.p, h->cap.p, total, hipMemcpyDeviceToHost, h->stream));
-    SFW_HIP(h, hipStreamSynchronize(h->stream));
+    // the scoring launch left everything in pinned memory (sfw_set_points_capture): points | counts | contact steps, no
+    // kernel, no copy — only the wait for the launch, if no fetch has waited for it yet
+    const size_t pts_bytes = sizeof(double) * 3 * static_cast<size_t>(S) * static_cast<size_t>(T);
+    if (!h->fetched) {
+      SFW_HIP(h, wait_stream(h));
+      stream_is_idle(h);
+    }
     const int32_t *np = reinterpret_cast<const int32_t *>(h->pin_cap.p + pts_bytes), *coll = np + T;
     std::memcpy(points_xyth, h->pin_cap.p + sizeof(double) * 3 * static_cast<size_t>(S) * static_cast<size_t>(first), sizeof(double) * 3 * S * n);
     for (size_t i = 0; i < n; ++i) {
