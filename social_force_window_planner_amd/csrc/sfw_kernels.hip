@@ -2082,7 +2082,10 @@ __device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *cons
             FCY = 56 * cap;  // byte offsets from px[] (immediates when CAP > 0)
   (void)FCX;
   (void)FCY;
-  const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, GROUPS, true, L.k.obs_lds != 0);
+  // (the cycle kernel's wave keeps the agents' constants in LDS like the GROUPS kernels: it has the CU's LDS to itself, and the
+  // 48-byte-per-agent load from memory at the top of every agent pass is latency nothing hides on a lone wave)
+  constexpr bool CONSTS_IN_LDS = GROUPS || CYCLE;
+  const lds_layout s(smem, A, cap, A, 1, O, NG, GROUPS ? L.n_grp_mem : 0, CONSTS_IN_LDS, true, L.k.obs_lds != 0);
   const int64_t first_local = CYCLE ? static_cast<int64_t>(bid) : item_base + xcd_contiguous(bid, nblk, static_cast<unsigned>(L.n_xcd));
   const sfm_consts<R> k0 = make_consts<R, true>(L);  // the prologue's; every step builds its own (below)
   // the five force constants stay in scalar registers for the rollout (a step's copy into VGPRs is five v_mov; read from the
@@ -2093,7 +2096,7 @@ __device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *cons
   constexpr bool F32 = sizeof(R) == 4;
   const int step_begin = L.step_begin, step_end = L.step_end;
   if constexpr (CYCLE) {  // (the block runs this wave for a scored sample only; the costmap's verdict is formed beside it)
-    stage_consts<GROUPS, GROUPS>(L, s, lane);
+    stage_consts<GROUPS, CONSTS_IN_LDS>(L, s, lane);
     if (lane == 0) s.dead[0] = 0;
     wave_sync();
   } else {
@@ -2358,7 +2361,7 @@ __device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *cons
 #else
     for (int sl = lane_s; sl < A; sl += WAVE) {
 #endif
-      const agent_k ak = GROUPS ? agent_k_lds(s, sl) : agent_k_global(agent_c, sl);
+      const agent_k ak = CONSTS_IN_LDS ? agent_k_lds(s, sl) : agent_k_global(agent_c, sl);
       double px = s.px[sl], py = s.py[sl], vx = s.vx[sl], vy = s.vy[sl];
       double nfx, nfy;
       int hg = s.hasgoal8[sl];
@@ -2505,7 +2508,7 @@ __device__ __forceinline__ void social_flat_wave(const sfw_launch &L, char *cons
         // A short scan: the agent's lane runs the sixteen segments itself, the points through the scalar cache (the rounds
         // of the task loop cost more than they spread; sfw_derive prices both)
         for (int a = lane; a < A; a += WAVE) {
-          const double rad = GROUPS ? s.ac[a].radius : agent_c[a].radius;
+          const double rad = CONSTS_IN_LDS ? s.ac[a].radius : agent_c[a].radius;
           double tx, ty, sc;
           obstacle_sums<R, SFW_FLAT_PIPELINED>(k, c, obs_global(c.obstacles), s.px[a], s.py[a], rad, tx, ty, sc);
           if (a == 0) {
@@ -3245,9 +3248,10 @@ hipError_t sfw_launch_argmin(const double *costs, const double *linvels, const d
 
 // ---- one launch per control cycle ------------------------------------------------------------------------------------
 static size_t cycle_k2_bytes(const sfw_launch &L, bool obs_lds) {
-  const wave_plan fl{1, 0, true};
   const bool social = L.A > 0 && !(L.A == 1 && L.O == 0 && L.NG == 0);
-  return social ? ((lds_bytes_for(fl, L.A, L.O, L.NG, L.n_grp_mem, obs_lds) + 15) & ~size_t(15)) : 0;
+  if (!social) return 0;
+  // the flat form's layout on 64-double planes, with the agents' constants staged (social_flat_wave<.., CYCLE>)
+  return (lds_layout(nullptr, L.A, 64, L.A, 1, L.O, L.NG, L.n_grp_mem, true, true, obs_lds).bytes + 15) & ~size_t(15);
 }
 // Does sfw_launch_cycle take this launch?  A whole (unshared, single-chunk) rollout of a small grid whose K2 would run the
 // flat form on 64-double planes, or has no pedestrians to integrate.  SFW_CYCLE_FUSED=0 in the environment (read at every
