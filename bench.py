@@ -402,6 +402,14 @@ def run_config(workload_name, precision, steps, warmup, ctx, scaling="weak", res
         one_step()
     state["xchg"].clear()
     k2_ms, k1_ms, k3_ms, all_ms, wall = [], [], [], [], []
+    # The interpreter's cyclic garbage collector stays out of the timed region: with torch imported a full (generation-2)
+    # collection walks millions of objects — 80 ms in the middle of twenty 1.3 ms steps (profiles/r06_bench.json's first
+    # recording had it in extra.cfg2_o64: ms_per_step 5.5 against a median of 1.34; worst_step_ms shows such a step).
+    import gc
+
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -423,6 +431,8 @@ def run_config(workload_name, precision, steps, warmup, ctx, scaling="weak", res
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     per_rank = None
     if dist is not None:
         cd = ctx["coll_device"]
@@ -455,6 +465,8 @@ def run_config(workload_name, precision, steps, warmup, ctx, scaling="weak", res
         "steps": steps,
         "n_scored_total": n_scored_total,
         "median_step_ms": float(np.median(wall)) * 1e3,
+        "worst_step_ms": float(np.max(wall)) * 1e3,
+        "worst_step_index": int(np.argmax(wall)),
         "k1_ms": float(np.mean(k1_ms)),
         "k2_ms": float(np.mean(k2_ms)),
         "k3_ms": float(np.mean(k3_ms)),
@@ -686,6 +698,8 @@ def extra_entry(name, precision, steps, warmup, ctx, verify_budget=0.0):
         "steps": steps,
         "ms_per_step": r["elapsed"] / steps * 1e3,
         "median_ms_per_step": r["median_step_ms"],
+        "worst_step_ms": r["worst_step_ms"],  # (a single slow step — a box hiccup — shows here and in value, not in the median)
+        "worst_step_index": r["worst_step_index"],
         "kernel_only_value": j.n_scored / (r["launch_ms"] * 1e-3),
         "kernel_ms": {"rollout": r["k1_ms"], "social": r["k2_ms"], "argmin": r["k3_ms"], "launch_total": r["launch_ms"]},
         "roofline_frac": rf["frac"],
